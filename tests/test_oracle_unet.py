@@ -1,0 +1,165 @@
+"""CPU: known-answer checks of the UNet / ControlNet / LoRA oracle (parity unpinned):
+parameter counts, diffusers key/shape list, op cross-checks against torch.nn.functional."""
+import math
+
+import pytest
+import torch
+
+from oracle import schedulers as osch
+from oracle import unet as ou
+
+torch.set_grad_enabled(False)
+
+
+
+
+def _resnet(cin, cout, temb):
+    n = 2 * cin + (cin * cout * 9 + cout) + (temb * cout + cout) + 2 * cout + (cout * cout * 9 + cout)
+    if cin != cout:
+        n += cin * cout + cout
+    return n
+
+
+def _transformer(c, ctx):
+    n = 2 * c + 2 * (c * c + c)  # norm, proj_in, proj_out
+    n += 3 * 2 * c  # 3 layer norms
+    n += 3 * c * c + (c * c + c)  # attn1
+    n += c * c + 2 * ctx * c + (c * c + c)  # attn2
+    n += (c * 8 * c + 8 * c) + (4 * c * c + c)  # GEGLU ff
+    return n
+
+
+def test_sd15_param_counts_by_formula():
+    cfg = ou.SD15
+    temb = cfg.time_embed_dim
+    n = 4 * 320 * 9 + 320 + (320 * temb + temb) + (temb * temb + temb)
+    cin = 320
+    for i, c in enumerate(cfg.block_out_channels):
+        for j in range(2):
+            n += _resnet(cin, c, temb)
+            cin = c
+            if cfg.attn_levels[i]:
+                n += _transformer(c, 768)
+        if i < 3:
+            n += c * c * 9 + c
+    enc_mid = n + 2 * _resnet(1280, 1280, temb) + _transformer(1280, 768)
+    n = enc_mid
+    skips = cfg.skip_channels()
+    assert skips == [320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280]
+    prev = 1280
+    for i, c in enumerate(reversed(cfg.block_out_channels)):
+        for j in range(3):
+            n += _resnet(prev + skips.pop(), c, temb)
+            prev = c
+            if cfg.attn_levels[3 - i]:
+                n += _transformer(c, 768)
+        if i < 3:
+            n += c * c * 9 + c
+    n += 2 * 320 + 320 * 4 * 9 + 4
+    assert n == 859_520_964
+    # ControlNet = encoder + mid + cond embedding + zero convs
+    ce = cfg.cond_embed_channels
+    m = enc_mid + 3 * ce[0] * 9 + ce[0]
+    for a, b in zip(ce[:-1], ce[1:]):
+        m += a * a * 9 + a + a * b * 9 + b
+    m += ce[-1] * 320 * 9 + 320
+    m += sum(c * c + c for c in cfg.skip_channels()) + 1280 * 1280 + 1280
+    assert m == 361_279_120
+    # LoRA r=4 on to_q/k/v/out of all 32 attentions: r*(14C+1536) per transformer block
+    lora = sum(4 * (14 * c + 2 * 768) for c in [320] * 5 + [640] * 5 + [1280] * 6)
+    assert lora == 797_184
+
+
+@pytest.mark.parametrize("cfg", [ou.TINY, ou.MNIST])
+def test_small_config_keys_and_forward(cfg):
+    p = ou.init_unet_params(cfg, seed=1)
+    # diffusers key families present (App. A.5)
+    for k in ("conv_in.weight", "time_embedding.linear_1.weight", "down_blocks.0.resnets.0.norm1.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+              "down_blocks.0.downsamplers.0.conv.weight", "mid_block.attentions.0.proj_out.bias",
+              "up_blocks.0.resnets.0.conv_shortcut.weight", "conv_norm_out.weight", "conv_out.bias"):
+        assert k in p, k
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.bias" not in p
+    B, h = 2, 16
+    x = torch.randn(B, cfg.in_channels, h, h)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim)
+    y = ou.unet_forward(p, cfg, x, torch.tensor(500), ctx)
+    assert y.shape == (B, cfg.out_channels, h, h) and torch.isfinite(y).all()
+    # scalar t == broadcast [B] t
+    y2 = ou.unet_forward(p, cfg, x, torch.tensor([500, 500]), ctx)
+    assert torch.allclose(y, y2, atol=1e-6)
+
+
+def test_lora_keys_and_zero_B_is_identity():
+    cfg = ou.TINY
+    p = ou.init_unet_params(cfg, seed=2)
+    lora0 = ou.init_lora_params(p, rank=4, zero_B=True)
+    lora = ou.init_lora_params(p, rank=4)
+    n_attn = sum(1 for k in p if k.endswith("attn1.to_q.weight")) * 2
+    assert len(lora) == n_attn * 4 * 2
+    assert ou.count_params(lora) == sum(
+        4 * (p[m + ".weight"].shape[0] + p[m + ".weight"].shape[1]) for m in ou.lora_target_modules(p))
+    x = torch.randn(1, 4, 8, 8)
+    ctx = torch.randn(1, 77, cfg.cross_attention_dim)
+    y = ou.unet_forward(p, cfg, x, torch.tensor(10), ctx)
+    y0 = ou.unet_forward({**p, **lora0}, cfg, x, torch.tensor(10), ctx)
+    y1 = ou.unet_forward({**p, **lora}, cfg, x, torch.tensor(10), ctx)
+    assert torch.equal(y, y0)
+    assert not torch.allclose(y, y1, atol=1e-5)
+    # merged weights W + s*B@A give the same function (what a fused GEMM tail computes)
+    merged = dict(p)
+    for m in ou.lora_target_modules(p):
+        merged[m + ".weight"] = p[m + ".weight"] + lora[m + ".lora_B.default.weight"] @ lora[m + ".lora_A.default.weight"]
+    ym = ou.unet_forward(merged, cfg, x, torch.tensor(10), ctx)
+    assert torch.allclose(ym, y1, atol=2e-5)
+
+
+def test_controlnet_shapes_and_residual_injection():
+    cfg = ou.TINY
+    up = ou.init_unet_params(cfg, seed=3)
+    cp = ou.init_controlnet_params(cfg, seed=4)
+    x = torch.randn(1, 4, 8, 8)
+    ctx = torch.randn(1, 77, cfg.cross_attention_dim)
+    cond = torch.randn(1, 3, 64, 64)
+    down, mid = ou.controlnet_forward(cp, cfg, x, torch.tensor(7), ctx, cond)
+    assert [d.shape[1] for d in down] == cfg.skip_channels()
+    assert [d.shape[-1] for d in down] == [8, 8, 8, 4, 4, 4, 2, 2, 2, 1, 1, 1]
+    assert mid.shape == (1, 256, 1, 1)
+    y0 = ou.unet_forward(up, cfg, x, torch.tensor(7), ctx)
+    y1 = ou.unet_forward(up, cfg, x, torch.tensor(7), ctx, down, mid)
+    assert not torch.allclose(y0, y1)
+    zc = ou.init_controlnet_params(cfg, seed=4, zero_init=True)
+    down0, mid0 = ou.controlnet_forward(zc, cfg, x, torch.tensor(7), ctx, cond)
+    assert all(float(d.abs().max()) == 0 for d in down0) and float(mid0.abs().max()) == 0
+
+
+def test_time_embedding_layout():
+    e = ou.timestep_embedding(torch.tensor([0, 1, 999]), 320)
+    assert e.shape == (3, 320)
+    assert torch.allclose(e[0, :160], torch.ones(160)) and torch.allclose(e[0, 160:], torch.zeros(160))
+    f1 = math.exp(-math.log(10000.0) * 1 / 160)
+    assert e[1, 1].item() == pytest.approx(math.cos(f1), rel=1e-6)
+    assert e[1, 161].item() == pytest.approx(math.sin(f1), rel=1e-6)
+
+
+def test_scheduler_tables_and_ddim():
+    s = osch.OracleScheduler(timestep_spacing="leading", steps_offset=1)
+    ac = s.alphas_cumprod
+    assert ac.shape == (1000,) and ac[0].item() == pytest.approx(1 - 0.00085, rel=1e-6)
+    assert ac[999].item() == pytest.approx(0.0046600, rel=2e-3)  # SD-1.5 terminal alpha-bar
+    s.set_timesteps(50)
+    assert s.timesteps[:3].tolist() == [981, 961, 941] and s.timesteps[-1].item() == 1
+    tr = osch.make_timesteps(20, spacing="trailing")
+    assert tr[0] == 999 and tr[-1] == 49 and len(tr) == 20
+    # DDIM with a perfect eps recovers x0 at the last step's alpha_prev = alpha[0]
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 8, 8, generator=g)
+    eps = torch.randn(1, 4, 8, 8, generator=g)
+    t = 981
+    x = ac[t].sqrt() * x0 + (1 - ac[t]).sqrt() * eps
+    xp = s.ddim_step(eps, t, x)
+    tp = t - 20
+    assert torch.allclose(xp, ac[tp].sqrt() * x0 + (1 - ac[tp]).sqrt() * eps, atol=1e-5)
+    cx, ce = s.ddim_coeffs(t)
+    assert torch.allclose(xp, cx * x + ce * eps, atol=1e-5)

@@ -1,0 +1,163 @@
+/* mrisr.h - C ABI of libmrisr.so: the MI355X (gfx950) denoiser hot path of
+ * Bernat-C/MRI-Diffusion-SuperResolution, behind the call surface the reference uses.
+ *
+ * What each entry point replaces in the reference (file:line under /root/reference):
+ *   mrisr_unet_forward        <- unet(latents, t, encoder_hidden_states=..., down_block_additional_residuals=...,
+ *                                     mid_block_additional_residual=...).sample      src/adapters/res_srdiff.py:73-78
+ *                                (diffusers UNet2DConditionModel; + down_intrablock_additional_residuals for T2I-Adapter)
+ *   mrisr_controlnet_forward  <- controlnet(latents, t, encoder_hidden_states=..., controlnet_cond=...,
+ *                                     return_dict=False)                             src/adapters/res_srdiff.py:65-70
+ *   mrisr_adapter_forward     <- Adapter_XL.forward                                  src/adapters/modules.py:146-157
+ *   mrisr_resshift_forward    <- get_res_shifting_latents                            src/adapters/res_srdiff.py:7-25
+ *   mrisr_sampler_*           <- the timestep loop of log_validation                 src/adapters/res_srdiff.py:63-96
+ *                                (Res-SRDiff reverse step :84-96, or the DDIM(eta=0) step BASELINE.json names)
+ *   mrisr_*_set_param         <- nn.Module.load_state_dict with diffusers / peft / reference key names
+ *
+ * Conventions
+ *   - every function returns 0 on success; otherwise mrisr_last_error() (thread-local) describes the failure.
+ *   - all tensors are caller-owned DEVICE memory described by mrisr_tensor (contiguous; NCHW like torch unless
+ *     layout says NHWC).  Kernels are enqueued on the caller's stream; nothing synchronises internally, and
+ *     nothing allocates inside *_forward after the first call for a given shape (hipGraph-capturable).
+ *   - a handle is bound to the device that was current at creation; handles are not thread-safe.
+ *   - no torch / C++ types cross this boundary.
+ */
+#ifndef MRISR_H
+#define MRISR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MRISR_F32 = 0, MRISR_BF16 = 1, MRISR_F16 = 2, MRISR_I64 = 3 } mrisr_dtype;
+typedef enum { MRISR_NCHW = 0, MRISR_NHWC = 1 } mrisr_layout;
+
+typedef struct {
+    void* data;        /* device pointer (host pointer only where a function says so) */
+    int32_t dtype;     /* mrisr_dtype */
+    int32_t layout;    /* mrisr_layout; ignored for ndim < 4 */
+    int32_t ndim;
+    int64_t shape[4];  /* logical NCHW order for 4-D image tensors: {B, C, H, W} */
+} mrisr_tensor;
+
+/* Mirror of the diffusers config keys the path depends on (SD-1.5 values in comments). */
+typedef struct {
+    int32_t in_channels;            /* 4 */
+    int32_t out_channels;           /* 4 */
+    int32_t num_levels;             /* 4 */
+    int32_t block_out_channels[4];  /* 320, 640, 1280, 1280 */
+    int32_t attn_levels[4];         /* 1, 1, 1, 0  (CrossAttn{Down,Up}Block2D at that level) */
+    int32_t layers_per_block;       /* 2 */
+    int32_t num_heads;              /* 8 (diffusers "attention_head_dim": 8) */
+    int32_t cross_attention_dim;    /* 768 */
+    int32_t norm_num_groups;        /* 32 */
+    float norm_eps;                 /* 1e-5 */
+    int32_t cond_channels;          /* ControlNet: 3 */
+    int32_t cond_embed_channels[4]; /* ControlNet: 16, 32, 96, 256 */
+    int32_t compute_dtype;          /* MRISR_BF16 (fast: bf16 storage, f32 accumulate/statistics) or
+                                       MRISR_F32 (parity: f32 storage, exact-f32 MFMA) */
+    int32_t lora_rank;              /* 0 = no LoRA; else rank of the peft adapters that will be set */
+    int32_t lora_fused;             /* 1: rank-r tail fused into the projection GEMMs; 0: merged into W at finalize */
+    int32_t flash_attention;        /* 1: fused flash kernel (bf16 only); 0: materialised scores */
+} mrisr_unet_cfg;
+
+typedef struct mrisr_model mrisr_model; /* UNet2DConditionModel or ControlNetModel */
+typedef struct mrisr_adapter mrisr_adapter;
+typedef struct mrisr_sampler mrisr_sampler;
+
+const char* mrisr_last_error(void);
+const char* mrisr_version(void);
+
+/* ---- model lifetime & weights ---------------------------------------------------------------- */
+int mrisr_unet_create(const mrisr_unet_cfg* cfg, mrisr_model** out);
+int mrisr_controlnet_create(const mrisr_unet_cfg* cfg, mrisr_model** out);
+void mrisr_model_destroy(mrisr_model* m);
+/* key: diffusers state-dict name, peft LoRA name (<module>.lora_A.default.weight /
+ * lora_B.default.weight; <module>.base_layer.weight accepted for wrapped layers).  data: f32, host or device
+ * (is_device), contiguous, torch shape.  Copied; the caller may free it afterwards. */
+int mrisr_model_set_param(mrisr_model* m, const char* key, const float* data, const int64_t* shape, int ndim,
+                          int is_device);
+int mrisr_model_set_lora_scale(mrisr_model* m, float scale); /* lora_alpha / r */
+/* Re-lays weights out for the kernels (NHWC filter order, fused QKV, GEGLU interleave, LoRA tails, ...).
+ * Must be called after the last set_param and before forward; may be called again after updating params. */
+int mrisr_model_finalize(mrisr_model* m, void* stream);
+int64_t mrisr_model_num_params(const mrisr_model* m);
+int64_t mrisr_model_workspace_bytes(const mrisr_model* m);
+
+/* ---- UNet2DConditionModel.forward ------------------------------------------------------------- */
+/* sample [B,Cin,h,w]; timestep: device int64, ndim 0 (broadcast) or [B]; ehs [B,L,Dctx] or NULL to reuse the
+ * projections cached by the previous call / mrisr_model_set_context; down_res: 0 or 12(=n_skips) tensors shaped like
+ * the skips; mid_res: NULL or [B,C_mid,h/8,w/8]; intrablock: 0 or num_levels tensors (T2I-Adapter features);
+ * out [B,Cout,h,w] in out->dtype. */
+int mrisr_unet_forward(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep,
+                       const mrisr_tensor* ehs, const mrisr_tensor* down_res, int n_down_res,
+                       const mrisr_tensor* mid_res, const mrisr_tensor* intrablock, int n_intrablock,
+                       mrisr_tensor* out, void* stream);
+/* Pre-compute the cross-attention K/V projections of a fixed prompt embedding (timestep-invariant). */
+int mrisr_model_set_context(mrisr_model* m, const mrisr_tensor* ehs, int latent_h, int latent_w, void* stream);
+int mrisr_model_num_skips(const mrisr_model* m);
+/* shape {B,C,H,W} of skip k for a latent of h x w (k == num_skips -> the mid block tensor) */
+int mrisr_model_skip_shape(const mrisr_model* m, int k, int B, int h, int w, int64_t shape[4]);
+
+/* ---- ControlNetModel.forward ------------------------------------------------------------------- */
+/* cond [B,3,8h,8w] or NULL to reuse the cached condition embedding; down_out: n_skips tensors, mid_out: 1. */
+int mrisr_controlnet_forward(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep,
+                             const mrisr_tensor* ehs, const mrisr_tensor* cond, float conditioning_scale,
+                             mrisr_tensor* down_out, int n_down_out, mrisr_tensor* mid_out, void* stream);
+int mrisr_controlnet_set_cond(mrisr_model* m, const mrisr_tensor* cond, void* stream);
+
+/* ---- T2I-Adapter (Adapter_XL, sk=True) ----------------------------------------------------------- */
+typedef struct {
+    int32_t channels[4]; /* 320, 640, 1280, 1280 */
+    int32_t nums_rb;     /* 3 */
+    int32_t cin;         /* 192 = 3*8*8 */
+    int32_t ksize;       /* 3 (1 also supported) */
+    int32_t use_conv;    /* 1: stride-2 conv downsample */
+    int32_t compute_dtype;
+} mrisr_adapter_cfg;
+int mrisr_adapter_create(const mrisr_adapter_cfg* cfg, mrisr_adapter** out);
+void mrisr_adapter_destroy(mrisr_adapter* a);
+int mrisr_adapter_set_param(mrisr_adapter* a, const char* key, const float* data, const int64_t* shape, int ndim,
+                            int is_device);
+int mrisr_adapter_finalize(mrisr_adapter* a, void* stream);
+/* x [B,3,8h,8w] -> 4 feature maps (caller-allocated, any dtype/layout) */
+int mrisr_adapter_forward(mrisr_adapter* a, const mrisr_tensor* x, mrisr_tensor* feats, int n_feats, void* stream);
+
+/* ---- scheduler math (f32 latents, elementwise) --------------------------------------------------- */
+/* x_t = sqrt(a_t) HR + (1-sqrt(a_t)) LR + sqrt(1-a_t) eps, a_t = alphas_cumprod[t]; t: device int64 0-dim or [B] */
+int mrisr_resshift_forward(const mrisr_tensor* hr, const mrisr_tensor* lr, const mrisr_tensor* noise,
+                           const float* alphas_cumprod_dev, const mrisr_tensor* timestep, mrisr_tensor* out,
+                           void* stream);
+
+/* ---- sampler: the timestep loop, one hipGraph per step -------------------------------------------- */
+typedef enum { MRISR_STEP_DDIM = 0, MRISR_STEP_RESSHIFT = 1 } mrisr_step_kind;
+/* timesteps: host int64[n_steps]; alphas_cumprod: host f32[n_train]; unet required, controlnet may be NULL. */
+int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_kind, const int64_t* timesteps,
+                         int n_steps, const float* alphas_cumprod, int n_train, mrisr_sampler** out);
+void mrisr_sampler_destroy(mrisr_sampler* s);
+/* Runs all steps on `stream`, updating latents [B,C,h,w] f32 NCHW in place.
+ *   lr_latents: RESSHIFT anchor (NULL for DDIM);  step_noise: RESSHIFT [n_steps-1 or more][B,C,h,w] f32 or NULL (then
+ *   the stochastic term is dropped);  ehs / cond / intrablock as in the forward calls (projected once, before step 0).
+ *   use_graph: capture step 0's launches into a hipGraph and replay it for the remaining steps. */
+int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tensor* lr_latents,
+                      const mrisr_tensor* step_noise, const mrisr_tensor* ehs, const mrisr_tensor* cond,
+                      const mrisr_tensor* intrablock, int n_intrablock, int use_graph, void* stream);
+
+/* ---- single-op entry points (used by the parity tests; same kernels the models launch) ------------ */
+int mrisr_op_conv3x3(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, const float* w_oihw_dev,
+                     const float* bias_dev, int cout, int stride, int upsample, int act, int splitk, int tile,
+                     mrisr_tensor* y_nhwc, void* stream);
+int mrisr_op_linear(const mrisr_tensor* x_rows, const float* w_dev, const float* bias_dev, int n, int act,
+                    int splitk, int tile, mrisr_tensor* y_rows, void* stream);
+int mrisr_op_groupnorm(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, const float* gamma_dev,
+                       const float* beta_dev, int groups, float eps, int silu, mrisr_tensor* y_nhwc, void* stream);
+int mrisr_op_layernorm(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, float eps,
+                       mrisr_tensor* y_rows, void* stream);
+/* q,k,v rows [B,N,H*d] (k,v: [B,Nk,H*d]) -> out [B,N,H*d]; flash=1 uses the fused kernel (bf16) */
+int mrisr_op_attention(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, int heads, int flash,
+                       mrisr_tensor* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRISR_H */

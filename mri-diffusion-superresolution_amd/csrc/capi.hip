@@ -1,0 +1,734 @@
+// C ABI (include/mrisr.h): thin extern "C" layer over Model, plus the sampler (per-step hipGraph), the
+// T2I-Adapter runtime and the single-op entry points the parity tests call.
+#include <cmath>
+#include <cstring>
+
+#include "model.h"
+
+using namespace mrisr;
+
+struct mrisr_model : public Model {};
+
+#define TRY(expr)            \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+#define API_BEGIN try {
+#define API_END                                              \
+    }                                                        \
+    catch (const std::exception& e) {                        \
+        set_error(std::string("exception: ") + e.what());    \
+        return 99;                                           \
+    }
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" {
+
+const char* mrisr_last_error(void) { return last_error_cstr(); }
+const char* mrisr_version(void) { return "mrisr 0.1 (gfx950)"; }
+
+static int create_model(const mrisr_unet_cfg* cfg, bool cn, mrisr_model** out) {
+    API_BEGIN
+    MRISR_REQUIRE(cfg && out, "null argument");
+    MRISR_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 4, "num_levels 1..4");
+    MRISR_REQUIRE(cfg->compute_dtype == MRISR_F32 || cfg->compute_dtype == MRISR_BF16, "compute dtype f32 or bf16");
+    const int bk = cfg->compute_dtype == MRISR_F32 ? 32 : 64;
+    for (int i = 0; i < cfg->num_levels; ++i) {
+        MRISR_REQUIRE(cfg->block_out_channels[i] % bk == 0, "block_out_channels must be multiples of the 128-byte K tile");
+        MRISR_REQUIRE(cfg->block_out_channels[i] % cfg->num_heads == 0 && (cfg->block_out_channels[i] / cfg->num_heads) % 4 == 0,
+                      "head dim must be a multiple of 4");
+        MRISR_REQUIRE(cfg->block_out_channels[i] % cfg->norm_num_groups == 0, "channels vs norm groups");
+    }
+    MRISR_REQUIRE(cfg->cross_attention_dim % bk == 0, "cross_attention_dim must be a multiple of the K tile");
+    int dev_count = 0;
+    MRISR_CHECK_HIP(hipGetDeviceCount(&dev_count));
+    MRISR_REQUIRE(dev_count > 0, "no HIP device: libmrisr has no CPU fallback");
+    auto* m = new mrisr_model();
+    m->cfg = *cfg;
+    m->is_controlnet = cn;
+    *out = m;
+    return 0;
+    API_END
+}
+int mrisr_unet_create(const mrisr_unet_cfg* cfg, mrisr_model** out) { return create_model(cfg, false, out); }
+int mrisr_controlnet_create(const mrisr_unet_cfg* cfg, mrisr_model** out) { return create_model(cfg, true, out); }
+void mrisr_model_destroy(mrisr_model* m) { delete m; }
+
+int mrisr_model_set_param(mrisr_model* m, const char* key, const float* data, const int64_t* shape, int ndim,
+                          int is_device) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->set_param(key, data, shape, ndim, is_device);
+    API_END
+}
+int mrisr_model_set_lora_scale(mrisr_model* m, float scale) {
+    MRISR_REQUIRE(m, "null handle");
+    m->lora_scale = scale;
+    m->finalized = false;
+    return 0;
+}
+int mrisr_model_finalize(mrisr_model* m, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    TRY(gemm_prepare());
+    return m->finalize((hipStream_t)stream);
+    API_END
+}
+int64_t mrisr_model_num_params(const mrisr_model* m) { return m ? m->num_params() : 0; }
+int64_t mrisr_model_workspace_bytes(const mrisr_model* m) {
+    return m ? (int64_t)(m->arena.buf.bytes + m->persist.bytes) : 0;
+}
+int mrisr_model_num_skips(const mrisr_model* m) { return m ? m->num_skips() : 0; }
+int mrisr_model_skip_shape(const mrisr_model* m, int k, int B, int h, int w, int64_t shape[4]) {
+    MRISR_REQUIRE(m, "null handle");
+    return m->skip_shape(k, B, h, w, shape);
+}
+
+int mrisr_unet_forward(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep,
+                       const mrisr_tensor* ehs, const mrisr_tensor* down_res, int n_down_res,
+                       const mrisr_tensor* mid_res, const mrisr_tensor* intrablock, int n_intrablock,
+                       mrisr_tensor* out, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->forward_unet(sample, timestep, ehs, down_res, n_down_res, mid_res, intrablock, n_intrablock, out,
+                           (hipStream_t)stream);
+    API_END
+}
+int mrisr_model_set_context(mrisr_model* m, const mrisr_tensor* ehs, int latent_h, int latent_w, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m && ehs, "null argument");
+    return m->set_context(ehs, (int)ehs->shape[0], latent_h, latent_w, (hipStream_t)stream);
+    API_END
+}
+int mrisr_controlnet_forward(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep,
+                             const mrisr_tensor* ehs, const mrisr_tensor* cond, float conditioning_scale,
+                             mrisr_tensor* down_out, int n_down_out, mrisr_tensor* mid_out, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->forward_controlnet(sample, timestep, ehs, cond, conditioning_scale, down_out, n_down_out, mid_out,
+                                 (hipStream_t)stream);
+    API_END
+}
+int mrisr_controlnet_set_cond(mrisr_model* m, const mrisr_tensor* cond, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m && cond, "null argument");
+    MRISR_REQUIRE(m->ctx_len > 0, "set the context (or run one forward) before caching the condition image");
+    return m->set_cond(cond, m->ctx_len, (hipStream_t)stream);
+    API_END
+}
+
+int mrisr_resshift_forward(const mrisr_tensor* hr, const mrisr_tensor* lr, const mrisr_tensor* noise,
+                           const float* alphas_cumprod_dev, const mrisr_tensor* timestep, mrisr_tensor* out,
+                           void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(hr && lr && noise && out && timestep && alphas_cumprod_dev, "null argument");
+    MRISR_REQUIRE(hr->dtype == MRISR_F32 && lr->dtype == MRISR_F32 && noise->dtype == MRISR_F32 && out->dtype == MRISR_F32,
+                  "f32 latents");
+    MRISR_REQUIRE(timestep->dtype == MRISR_I64, "int64 timesteps");
+    const int B = (int)hr->shape[0];
+    long long per = 1;
+    for (int i = 1; i < hr->ndim; ++i) per *= hr->shape[i];
+    const int scalar = timestep->ndim == 0 || timestep->shape[0] == 1;
+    return launch_resshift_forward((const float*)hr->data, (const float*)lr->data, (const float*)noise->data,
+                                   alphas_cumprod_dev, (const long long*)timestep->data, scalar, (float*)out->data, B,
+                                   per, (hipStream_t)stream);
+    API_END
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// sampler
+// =================================================================================================
+__global__ void load_t_kernel(long long* cur_t, const long long* table, const int* step) { *cur_t = table[*step]; }
+
+struct mrisr_sampler {
+    mrisr_model* unet = nullptr;
+    mrisr_model* cnet = nullptr;
+    int kind = 0, n_steps = 0;
+    DevBuf d_ts, d_coef, d_step, d_curt, d_eps;
+    std::vector<std::unique_ptr<DevBuf>> res_bufs;   // ControlNet -> UNet residuals (NHWC, compute dtype)
+    std::vector<std::unique_ptr<DevBuf>> intra_bufs;  // adapter features converted once
+    hipGraphExec_t exec = nullptr;
+    std::string graph_key;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    ~mrisr_sampler() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_out) (void)hipEventDestroy(ev_out);
+    }
+};
+
+extern "C" {
+
+int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_kind, const int64_t* timesteps,
+                         int n_steps, const float* alphas_cumprod, int n_train, mrisr_sampler** out) {
+    API_BEGIN
+    MRISR_REQUIRE(unet && timesteps && alphas_cumprod && out && n_steps > 0, "bad argument");
+    MRISR_REQUIRE(!controlnet || controlnet->cfg.compute_dtype == unet->cfg.compute_dtype, "UNet/ControlNet dtype mismatch");
+    std::unique_ptr<mrisr_sampler> s(new mrisr_sampler());
+    s->unet = unet;
+    s->cnet = controlnet;
+    s->kind = step_kind;
+    s->n_steps = n_steps;
+    std::vector<long long> ts(timesteps, timesteps + n_steps);
+    std::vector<float> coef((size_t)n_steps * 4, 0.f);
+    for (int i = 0; i < n_steps; ++i) {
+        const long long t = ts[i];
+        MRISR_REQUIRE(t >= 0 && t < n_train, "timestep out of range");
+        const double a_t = alphas_cumprod[t];
+        if (step_kind == MRISR_STEP_DDIM) {
+            // t_prev = t - T/n; alpha_prev = alpha[t_prev] or alpha[0] (set_alpha_to_one=False)
+            const long long tp = t - n_train / n_steps;
+            const double a_p = tp >= 0 ? alphas_cumprod[tp] : alphas_cumprod[0];
+            coef[2 * i] = (float)std::sqrt(a_p / a_t);
+            coef[2 * i + 1] = (float)(std::sqrt(1.0 - a_p) - std::sqrt(a_p * (1.0 - a_t) / a_t));
+        } else {
+            // reference res_srdiff.py:83-96: prev_t = timesteps[i+1] or 0; last step uses alpha[0] and no noise
+            const long long tp = i + 1 < n_steps ? ts[i + 1] : 0;
+            const double a_p = alphas_cumprod[tp];
+            coef[4 * i] = (float)std::sqrt(a_t);
+            coef[4 * i + 1] = (float)std::sqrt(1.0 - a_t);
+            coef[4 * i + 2] = (float)std::sqrt(a_p);
+            coef[4 * i + 3] = tp > 0 ? (float)std::sqrt((1.0 - a_p) / (1.0 - a_t) * (1.0 - a_t / a_p)) : 0.f;
+        }
+    }
+    TRY(s->d_ts.reserve(sizeof(long long) * n_steps, false));
+    TRY(s->d_coef.reserve(sizeof(float) * coef.size(), false));
+    TRY(s->d_step.reserve(16, true));
+    TRY(s->d_curt.reserve(16, true));
+    MRISR_CHECK_HIP(hipMemcpy(s->d_ts.p, ts.data(), sizeof(long long) * n_steps, hipMemcpyHostToDevice));
+    MRISR_CHECK_HIP(hipMemcpy(s->d_coef.p, coef.data(), sizeof(float) * coef.size(), hipMemcpyHostToDevice));
+    *out = s.release();
+    return 0;
+    API_END
+}
+void mrisr_sampler_destroy(mrisr_sampler* s) { delete s; }
+
+int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tensor* lr_latents,
+                      const mrisr_tensor* step_noise, const mrisr_tensor* ehs, const mrisr_tensor* cond,
+                      const mrisr_tensor* intrablock, int n_intrablock, int use_graph, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(s && latents && ehs, "null argument");
+    MRISR_REQUIRE(latents->ndim == 4 && latents->dtype == MRISR_F32 && latents->layout == MRISR_NCHW, "latents: f32 NCHW");
+    MRISR_REQUIRE(s->kind == MRISR_STEP_DDIM || lr_latents, "Res-SRDiff needs the LR anchor latents");
+    MRISR_REQUIRE(!s->cnet || cond, "ControlNet needs the condition image");
+    hipStream_t user = (hipStream_t)stream;
+    hipStream_t st = user;
+    Model& U = *s->unet;
+    const int B = (int)latents->shape[0], h = (int)latents->shape[2], w = (int)latents->shape[3];
+    const int L = (int)ehs->shape[1];
+    const long long n = (long long)B * latents->shape[1] * h * w;
+    const int cdt = U.cfg.compute_dtype;
+    const int esz = dtype_size(cdt);
+
+    if (use_graph && user == nullptr) {
+        // the legacy default stream cannot be captured: run on an internal stream fenced by events
+        if (!s->own_stream) {
+            MRISR_CHECK_HIP(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+            MRISR_CHECK_HIP(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+            MRISR_CHECK_HIP(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+        }
+        st = s->own_stream;
+        MRISR_CHECK_HIP(hipEventRecord(s->ev_in, user));
+        MRISR_CHECK_HIP(hipStreamWaitEvent(st, s->ev_in, 0));
+    }
+
+    // ---- one-time (per run) timestep-invariant work: context projections, condition embedding, features ----
+    TRY(gemm_prepare());
+    TRY(U.set_context(ehs, B, h, w, st));
+    std::vector<mrisr_tensor> down_t;
+    mrisr_tensor mid_t{};
+    int ns = 0;
+    if (s->cnet) {
+        Model& C = *s->cnet;
+        TRY(C.set_context(ehs, B, h, w, st));
+        TRY(C.set_cond(cond, L, st));
+        ns = C.num_skips();
+        s->res_bufs.resize(ns + 1);
+        down_t.resize(ns);
+        for (int k = 0; k <= ns; ++k) {
+            mrisr_tensor t{};
+            t.ndim = 4; t.dtype = cdt; t.layout = MRISR_NHWC;
+            C.skip_shape(k, B, h, w, t.shape);
+            if (!s->res_bufs[k]) s->res_bufs[k].reset(new DevBuf());
+            TRY(s->res_bufs[k]->reserve((size_t)t.shape[0] * t.shape[1] * t.shape[2] * t.shape[3] * esz, false));
+            t.data = s->res_bufs[k]->p;
+            if (k < ns) down_t[k] = t; else mid_t = t;
+        }
+    }
+    std::vector<mrisr_tensor> intra(n_intrablock);
+    s->intra_bufs.resize(n_intrablock);
+    for (int i = 0; i < n_intrablock; ++i) {
+        const mrisr_tensor& f = intrablock[i];
+        MRISR_REQUIRE(f.ndim == 4, "adapter feature rank");
+        intra[i] = f;
+        if (f.layout == MRISR_NHWC && f.dtype == cdt) continue;
+        if (!s->intra_bufs[i]) s->intra_bufs[i].reset(new DevBuf());
+        TRY(s->intra_bufs[i]->reserve((size_t)f.shape[0] * f.shape[1] * f.shape[2] * f.shape[3] * esz, false));
+        if (cdt == MRISR_F32) TRY(launch_nchw_to_nhwc<float>(f.data, f.dtype, s->intra_bufs[i]->p, (int)f.shape[0], (int)f.shape[1], (int)f.shape[2], (int)f.shape[3], st));
+        else TRY(launch_nchw_to_nhwc<bf16>(f.data, f.dtype, s->intra_bufs[i]->p, (int)f.shape[0], (int)f.shape[1], (int)f.shape[2], (int)f.shape[3], st));
+        intra[i].data = s->intra_bufs[i]->p;
+        intra[i].layout = MRISR_NHWC;
+        intra[i].dtype = cdt;
+    }
+    TRY(s->d_eps.reserve((size_t)n * sizeof(float), false));
+    MRISR_CHECK_HIP(hipMemsetAsync(s->d_step.p, 0, 16, st));
+
+    mrisr_tensor tt{};
+    tt.data = s->d_curt.p; tt.dtype = MRISR_I64; tt.ndim = 0;
+    mrisr_tensor eps_t = *latents;
+    eps_t.data = s->d_eps.p;
+    const int* step = static_cast<const int*>(s->d_step.p);
+
+    auto body = [&]() -> int {
+        hipLaunchKernelGGL(load_t_kernel, dim3(1), dim3(1), 0, st, static_cast<long long*>(s->d_curt.p),
+                           static_cast<const long long*>(s->d_ts.p), step);
+        if (s->cnet)
+            TRY(s->cnet->forward_controlnet(latents, &tt, nullptr, nullptr, 1.0f, down_t.data(), ns, &mid_t, st));
+        TRY(U.forward_unet(latents, &tt, nullptr, s->cnet ? down_t.data() : nullptr, ns, s->cnet ? &mid_t : nullptr,
+                           intra.data(), n_intrablock, &eps_t, st));
+        if (s->kind == MRISR_STEP_DDIM)
+            TRY(launch_ddim_step((float*)latents->data, (const float*)s->d_eps.p, (const float*)s->d_coef.p, step, n, st));
+        else
+            TRY(launch_resshift_step((float*)latents->data, (const float*)s->d_eps.p, (const float*)lr_latents->data,
+                                     step_noise ? (const float*)step_noise->data : nullptr, (const float*)s->d_coef.p, step, n, st));
+        return launch_advance_step(static_cast<int*>(s->d_step.p), st);
+    };
+
+    if (!use_graph) {
+        for (int i = 0; i < s->n_steps; ++i) TRY(body());
+    } else {
+        char key[160];
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%p,%p,%p,%d", B, h, w, L, latents->data, lr_latents ? lr_latents->data : nullptr,
+                 step_noise ? step_noise->data : nullptr, n_intrablock);
+        if (!s->exec || s->graph_key != key) {
+            if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+            // workspaces are planned (set_context above), so the captured body performs launches only
+            hipGraph_t graph = nullptr;
+            MRISR_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = body();
+            hipError_t e = hipStreamEndCapture(st, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            MRISR_CHECK_HIP(e);
+            MRISR_CHECK_HIP(hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            s->graph_key = key;
+        }
+        for (int i = 0; i < s->n_steps; ++i) MRISR_CHECK_HIP(hipGraphLaunch(s->exec, st));
+    }
+    if (st != user) {
+        MRISR_CHECK_HIP(hipEventRecord(s->ev_out, st));
+        MRISR_CHECK_HIP(hipStreamWaitEvent(user, s->ev_out, 0));
+    }
+    return 0;
+    API_END
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// T2I-Adapter (reference src/adapters/modules.py:114-157, sk=True)
+// =================================================================================================
+struct AdBlock {
+    bool down = false, has_in = false;
+    ConvW down_w, in_w, b1, b2;
+    int in_c = 0, out_c = 0;
+};
+struct mrisr_adapter {
+    mrisr_adapter_cfg cfg{};
+    std::map<std::string, RawParam> raw;
+    std::vector<std::unique_ptr<DevBuf>> packed;
+    ConvW conv_in;
+    std::vector<AdBlock> blocks;
+    Arena arena;
+    bool finalized = false;
+};
+
+template <typename T>
+struct AdRunner {
+    mrisr_adapter& a;
+    hipStream_t st;
+    bool dry;
+    Act new_act(int B, int H, int W, int C) {
+        Act x; x.B = B; x.H = H; x.W = W; x.C = C;
+        x.p = a.arena.alloc(x.numel() * sizeof(T));
+        if (!x.p) set_error("adapter workspace exhausted");
+        return x;
+    }
+    int conv(const Act& x, const ConvW& cw, int stride, int act, const Act* resid, Act* out) {
+        MRISR_REQUIRE(cw.cin == x.C, "adapter conv channel mismatch");
+        const int Ho = (x.H - 1) / stride + 1, Wo = (x.W - 1) / stride + 1;
+        *out = new_act(x.B, cw.ks == 3 ? Ho : x.H, cw.ks == 3 ? Wo : x.W, cw.cout);
+        if (!out->p) return 7;
+        GemmArgs g;
+        g.a0 = x.p; g.c0 = x.C; g.lda0 = x.C;
+        g.w = cw.w; g.N = cw.cout; g.bias = cw.b; g.act = act;
+        if (cw.ks == 3) {
+            g.conv = 1; g.B = x.B; g.Hin = x.H; g.Win = x.W; g.Hout = Ho; g.Wout = Wo; g.stride = stride;
+            g.M = x.B * Ho * Wo; g.K = 9 * x.C;
+        } else {
+            MRISR_REQUIRE(stride == 1, "1x1 conv stride");
+            g.M = (int)x.rows(); g.K = x.C;
+        }
+        if (resid) { g.resid = resid->p; g.ldr = resid->C; }
+        g.out = out->p; g.ldo = cw.cout;
+        g.splitk = gemm_workspace_splitk(g);
+        if (g.splitk > 1) {
+            g.partial = static_cast<float*>(a.arena.alloc((size_t)g.splitk * g.M * g.N * sizeof(float)));
+            if (!g.partial) return 7;
+        }
+        if (dry) return 0;
+        return launch_gemm<T>(g, st);
+    }
+    int forward(const mrisr_tensor& x, mrisr_tensor* feats, int n_feats) {
+        a.arena.reset();
+        const int B = (int)x.shape[0], C = (int)x.shape[1], H = (int)x.shape[2], W = (int)x.shape[3];
+        MRISR_REQUIRE(H % 8 == 0 && W % 8 == 0 && C * 64 == a.cfg.cin, "adapter input must be [B, cin/64, 8h, 8w]");
+        Act u = new_act(B, H / 8, W / 8, C * 64);
+        if (!u.p) return 7;
+        if (!dry) TRY(launch_pixel_unshuffle_nchw<T>(x.data, x.dtype, u.p, B, C, H, W, 8, st));
+        Act cur;
+        TRY(conv(u, a.conv_in, 1, ACT_NONE, nullptr, &cur));
+        int fi = 0;
+        for (size_t k = 0; k < a.blocks.size(); ++k) {
+            AdBlock& b = a.blocks[k];
+            Act y;
+            if (b.down) { TRY(conv(cur, b.down_w, 2, ACT_NONE, nullptr, &y)); cur = y; }
+            if (b.has_in) { TRY(conv(cur, b.in_w, 1, ACT_NONE, nullptr, &y)); cur = y; }
+            Act hmid;
+            TRY(conv(cur, b.b1, 1, ACT_RELU, nullptr, &hmid));
+            TRY(conv(hmid, b.b2, 1, ACT_NONE, &cur, &y));
+            cur = y;
+            if ((k + 1) % a.cfg.nums_rb == 0) {
+                MRISR_REQUIRE(fi < n_feats, "too few feature outputs");
+                const mrisr_tensor& f = feats[fi++];
+                MRISR_REQUIRE(f.ndim == 4 && f.shape[0] == cur.B && f.shape[1] == cur.C && f.shape[2] == cur.H && f.shape[3] == cur.W,
+                              "adapter feature output shape");
+                if (!dry) {
+                    if (f.layout == MRISR_NHWC) {
+                        MRISR_REQUIRE(f.dtype == a.cfg.compute_dtype, "NHWC feature outputs use the compute dtype");
+                        MRISR_CHECK_HIP(hipMemcpyAsync(f.data, cur.p, cur.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
+                    } else {
+                        TRY(launch_nhwc_to_nchw<T>(cur.p, f.data, f.dtype, cur.B, cur.C, cur.H, cur.W, 1.0f, st));
+                    }
+                }
+            }
+        }
+        return 0;
+    }
+};
+
+template <typename T>
+static int adapter_finalize_t(mrisr_adapter& a, hipStream_t st) {
+    a.packed.clear();
+    a.blocks.clear();
+    int err = 0;
+    auto conv = [&](const std::string& name) {
+        ConvW c;
+        auto it = a.raw.find(name + ".weight");
+        if (it == a.raw.end()) { set_error("missing parameter: " + name + ".weight"); err = 3; return c; }
+        const RawParam& w = it->second;
+        c.cout = (int)w.shape[0]; c.cin = (int)w.shape[1]; c.ks = (int)w.shape[2];
+        a.packed.emplace_back(new DevBuf());
+        if (a.packed.back()->reserve((size_t)w.numel() * sizeof(T), false)) { err = 4; return c; }
+        c.w = a.packed.back()->p;
+        if (launch_pack_conv3x3<T>(static_cast<const float*>(w.data->p), c.w, c.cout, c.cin, c.ks, st)) err = 5;
+        auto ib = a.raw.find(name + ".bias");
+        c.b = ib == a.raw.end() ? nullptr : static_cast<const float*>(ib->second.data->p);
+        return c;
+    };
+    a.conv_in = conv("conv_in");
+    int k = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < a.cfg.nums_rb; ++j, ++k) {
+            AdBlock b;
+            const std::string n = "body." + std::to_string(k);
+            b.out_c = a.cfg.channels[i];
+            b.in_c = (i > 0 && j == 0) ? a.cfg.channels[i - 1] : b.out_c;
+            b.down = (i > 0 && j == 0);
+            if (b.down) {
+                if (!a.cfg.use_conv) { set_error("avg-pool downsample (use_conv=False) is not built"); return 8; }
+                b.down_w = conv(n + ".down_opt.op");
+            }
+            if (a.raw.count(n + ".in_conv.weight")) { b.has_in = true; b.in_w = conv(n + ".in_conv"); }
+            else if (b.in_c != b.out_c) { set_error("missing parameter: " + n + ".in_conv.weight"); return 3; }
+            if (a.raw.count(n + ".skep.weight")) {
+                // reference quirk: sk=False cannot run in the reference either
+                set_error("Adapter_XL with sk=False is not runnable in the reference (channel mismatch in skep); use sk=True");
+                return 8;
+            }
+            b.b1 = conv(n + ".block1");
+            b.b2 = conv(n + ".block2");
+            a.blocks.push_back(b);
+        }
+    if (err) return err;
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    a.finalized = true;
+    return 0;
+}
+
+extern "C" {
+
+int mrisr_adapter_create(const mrisr_adapter_cfg* cfg, mrisr_adapter** out) {
+    API_BEGIN
+    MRISR_REQUIRE(cfg && out, "null argument");
+    MRISR_REQUIRE(cfg->compute_dtype == MRISR_F32 || cfg->compute_dtype == MRISR_BF16, "compute dtype");
+    MRISR_REQUIRE(cfg->ksize == 1 || cfg->ksize == 3, "ksize 1 or 3");
+    auto* a = new mrisr_adapter();
+    a->cfg = *cfg;
+    *out = a;
+    return 0;
+    API_END
+}
+void mrisr_adapter_destroy(mrisr_adapter* a) { delete a; }
+int mrisr_adapter_set_param(mrisr_adapter* a, const char* key, const float* data, const int64_t* shape, int ndim,
+                            int is_device) {
+    API_BEGIN
+    MRISR_REQUIRE(a && key && data, "null argument");
+    RawParam rp;
+    rp.shape.assign(shape, shape + ndim);
+    rp.data = std::make_shared<DevBuf>();
+    TRY(rp.data->reserve((size_t)rp.numel() * sizeof(float), false));
+    MRISR_CHECK_HIP(hipMemcpy(rp.data->p, data, (size_t)rp.numel() * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    a->raw[key] = rp;
+    a->finalized = false;
+    return 0;
+    API_END
+}
+int mrisr_adapter_finalize(mrisr_adapter* a, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(a, "null handle");
+    TRY(gemm_prepare());
+    if (a->cfg.compute_dtype == MRISR_F32) return adapter_finalize_t<float>(*a, (hipStream_t)stream);
+    return adapter_finalize_t<bf16>(*a, (hipStream_t)stream);
+    API_END
+}
+int mrisr_adapter_forward(mrisr_adapter* a, const mrisr_tensor* x, mrisr_tensor* feats, int n_feats, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(a && x && feats && a->finalized, "adapter not finalized / null argument");
+    MRISR_REQUIRE(x->ndim == 4 && x->layout == MRISR_NCHW, "adapter input: NCHW image");
+    hipStream_t st = (hipStream_t)stream;
+    // size the arena with a dry pass (exact), then run
+    int rc;
+    a->arena.dry = true; a->arena.reset(); a->arena.peak = 0;
+    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, true}; rc = r.forward(*x, feats, n_feats); }
+    else { AdRunner<bf16> r{*a, st, true}; rc = r.forward(*x, feats, n_feats); }
+    a->arena.dry = false;
+    if (rc) return rc;
+    TRY(a->arena.buf.reserve(a->arena.peak + 4096, false));
+    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, false}; return r.forward(*x, feats, n_feats); }
+    AdRunner<bf16> r{*a, st, false};
+    return r.forward(*x, feats, n_feats);
+    API_END
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// single-op entry points (parity tests drive the very kernels the models launch)
+// =================================================================================================
+template <typename T>
+__global__ void rows_to_heads_kernel(const T* x, T* dst, int B, int N, int H, int hd, int npad, int dpad, int tr) {
+    const long long total = (long long)B * N * H * hd;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int dd = (int)(i % hd);
+        const int h = (int)((i / hd) % H);
+        const int tok = (int)((i / ((long long)hd * H)) % N);
+        const int b = (int)(i / ((long long)hd * H * N));
+        const size_t bh = (size_t)b * H + h;
+        if (!tr) dst[(bh * npad + tok) * dpad + dd] = x[i];
+        else dst[(bh * dpad + dd) * npad + tok] = x[i];
+    }
+}
+
+template <typename T>
+static int op_conv3x3_t(const mrisr_tensor* x, const mrisr_tensor* x2, const float* w, const float* bias, int cout,
+                        int stride, int ups, int act, int splitk, mrisr_tensor* y, hipStream_t st) {
+    const int B = (int)x->shape[0], C0 = (int)x->shape[1], H = (int)x->shape[2], W = (int)x->shape[3];
+    const int C1 = x2 ? (int)x2->shape[1] : 0;
+    const int Cin = C0 + C1;
+    DevBuf wp, part;
+    TRY(wp.reserve((size_t)cout * Cin * 9 * sizeof(T), false));
+    TRY(launch_pack_conv3x3<T>(w, wp.p, cout, Cin, 3, st));
+    GemmArgs g;
+    g.a0 = x->data; g.c0 = C0; g.lda0 = C0;
+    if (x2) { g.a1 = x2->data; g.c1 = C1; g.lda1 = C1; }
+    const int Hc = H << ups, Wc = W << ups;
+    g.conv = 1; g.B = B; g.Hin = H; g.Win = W; g.Hout = (Hc - 1) / stride + 1; g.Wout = (Wc - 1) / stride + 1;
+    g.stride = stride; g.ups = ups;
+    MRISR_REQUIRE(y->shape[1] == cout && y->shape[2] == g.Hout && y->shape[3] == g.Wout, "conv output shape");
+    g.w = wp.p; g.M = B * g.Hout * g.Wout; g.N = cout; g.K = 9 * Cin; g.bias = bias; g.act = act;
+    g.out = y->data; g.ldo = cout;
+    g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
+    if (g.splitk > 1) {
+        TRY(part.reserve((size_t)g.splitk * g.M * g.N * sizeof(float), false));
+        g.partial = static_cast<float*>(part.p);
+    }
+    TRY(launch_gemm<T>(g, st));
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" void mrisr_debug_force_tile(int t);
+
+template <typename T>
+static int op_attention_t(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, int H, int flash,
+                          mrisr_tensor* out, hipStream_t st) {
+    const int B = (int)q->shape[0], N = (int)q->shape[1], C = (int)q->shape[2], Nk = (int)k->shape[1];
+    const int hd = C / H;
+    constexpr int BK = 128 / (int)sizeof(T);
+    const bool use_flash = flash && sizeof(T) == 2;
+    const int dpad = round_up(hd, use_flash ? 32 : BK), npad = round_up(N, 64), nkpad = round_up(Nk, 64);
+    DevBuf qb, kb, vb, sb, pb;
+    TRY(qb.reserve((size_t)B * H * npad * dpad * sizeof(T), true));
+    TRY(kb.reserve((size_t)B * H * nkpad * dpad * sizeof(T), true));
+    TRY(vb.reserve((size_t)B * H * dpad * nkpad * sizeof(T), true));
+    auto conv = [&](const mrisr_tensor* x, void* dst, int n, int np, int tr) {
+        hipLaunchKernelGGL(rows_to_heads_kernel<T>, dim3(1024), dim3(256), 0, st, static_cast<const T*>(x->data),
+                           static_cast<T*>(dst), B, n, H, hd, np, dpad, tr);
+    };
+    conv(q, qb.p, N, npad, 0);
+    conv(k, kb.p, Nk, nkpad, 0);
+    conv(v, vb.p, Nk, nkpad, 1);
+    MRISR_CHECK_HIP(hipGetLastError());
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (use_flash) {
+        AttnArgs a;
+        a.q = qb.p; a.k = kb.p; a.vt = vb.p; a.out = out->data;
+        a.B = B; a.H = H; a.nq = N; a.nk = Nk; a.nkpad = nkpad; a.hd = hd; a.dpad = dpad; a.scale = scale;
+        TRY(launch_attention_bf16(a, st));
+    } else {
+        const int BH = B * H;
+        TRY(sb.reserve((size_t)BH * N * nkpad * sizeof(float), false));
+        void* P = sb.p;
+        if (sizeof(T) == 2) { TRY(pb.reserve((size_t)BH * N * nkpad * sizeof(T), false)); P = pb.p; }
+        GemmArgs g;
+        g.a0 = qb.p; g.c0 = dpad; g.lda0 = dpad; g.a_bs = (long long)npad * dpad;
+        g.w = kb.p; g.w_bs = (long long)nkpad * dpad; g.M = N; g.N = nkpad; g.K = dpad; g.batch = BH; g.alpha = scale;
+        g.out_mode = OUT_F32; g.out = sb.p; g.ldo = nkpad; g.o_bs = (long long)N * nkpad;
+        TRY(launch_gemm<T>(g, st));
+        TRY(launch_softmax_rows<T>(static_cast<const float*>(sb.p), nkpad, P, nkpad, (long long)BH * N, Nk, st));
+        GemmArgs o;
+        o.a0 = P; o.c0 = nkpad; o.lda0 = nkpad; o.a_bs = (long long)N * nkpad;
+        o.w = vb.p; o.w_bs = (long long)dpad * nkpad; o.M = N; o.N = hd; o.K = nkpad; o.batch = BH;
+        o.heads = H; o.o_bs = (long long)N * C; o.o_hs = hd; o.out = out->data; o.ldo = C;
+        TRY(launch_gemm<T>(o, st));
+    }
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+
+extern "C" {
+
+static int op_dtype_ok(const mrisr_tensor* x) {
+    MRISR_REQUIRE(x && (x->dtype == MRISR_F32 || x->dtype == MRISR_BF16), "op tensors: f32 or bf16");
+    return 0;
+}
+
+int mrisr_op_conv3x3(const mrisr_tensor* x, const mrisr_tensor* x2, const float* w_oihw_dev, const float* bias_dev,
+                     int cout, int stride, int upsample, int act, int splitk, int tile, mrisr_tensor* y,
+                     void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    TRY(gemm_prepare());
+    MRISR_REQUIRE(x->layout == MRISR_NHWC && y && y->layout == MRISR_NHWC && y->dtype == x->dtype, "NHWC in/out, same dtype");
+    mrisr_debug_force_tile(tile);
+    int rc = x->dtype == MRISR_F32
+                 ? op_conv3x3_t<float>(x, x2, w_oihw_dev, bias_dev, cout, stride, upsample, act, splitk, y, (hipStream_t)stream)
+                 : op_conv3x3_t<bf16>(x, x2, w_oihw_dev, bias_dev, cout, stride, upsample, act, splitk, y, (hipStream_t)stream);
+    mrisr_debug_force_tile(0);
+    return rc;
+    API_END
+}
+
+int mrisr_op_linear(const mrisr_tensor* x, const float* w_dev, const float* bias_dev, int n, int act, int splitk,
+                    int tile, mrisr_tensor* y, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    TRY(gemm_prepare());
+    MRISR_REQUIRE(x->ndim == 2 && y && y->ndim == 2 && y->dtype == x->dtype, "rows in/out");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)x->shape[0], K = (int)x->shape[1];
+    const bool f32 = x->dtype == MRISR_F32;
+    const int esz = f32 ? 4 : 2;
+    DevBuf wp, part, bp;
+    TRY(wp.reserve((size_t)n * K * esz, false));
+    const bool geglu = act == ACT_GEGLU;
+    if (f32) TRY(launch_pack_rows<float>(w_dev, n, K, wp.p, K, 0, 0, geglu ? 1 : 0, n / 2, 1.0f, st));
+    else TRY(launch_pack_rows<bf16>(w_dev, n, K, wp.p, K, 0, 0, geglu ? 1 : 0, n / 2, 1.0f, st));
+    const float* bias = bias_dev;
+    if (geglu && bias_dev) {
+        TRY(bp.reserve((size_t)n * sizeof(float), false));
+        TRY(launch_pack_bias_geglu(bias_dev, static_cast<float*>(bp.p), n / 2, st));
+        bias = static_cast<const float*>(bp.p);
+    }
+    GemmArgs g;
+    g.a0 = x->data; g.c0 = K; g.lda0 = K; g.w = wp.p; g.M = M; g.N = n; g.K = K; g.bias = bias; g.act = act;
+    g.out = y->data; g.ldo = (int)y->shape[1];
+    g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
+    if (g.splitk > 1) {
+        TRY(part.reserve((size_t)g.splitk * M * n * sizeof(float), false));
+        g.partial = static_cast<float*>(part.p);
+    }
+    mrisr_debug_force_tile(tile);
+    int rc = f32 ? launch_gemm<float>(g, st) : launch_gemm<bf16>(g, st);
+    mrisr_debug_force_tile(0);
+    if (rc) return rc;
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+    API_END
+}
+
+int mrisr_op_groupnorm(const mrisr_tensor* x, const mrisr_tensor* x2, const float* gamma_dev, const float* beta_dev,
+                       int groups, float eps, int silu, mrisr_tensor* y, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    MRISR_REQUIRE(x->layout == MRISR_NHWC && y && y->dtype == x->dtype, "NHWC in/out, same dtype");
+    hipStream_t st = (hipStream_t)stream;
+    GroupNormArgs a;
+    a.x0 = x->data; a.c0 = (int)x->shape[1];
+    if (x2) { a.x1 = x2->data; a.c1 = (int)x2->shape[1]; }
+    a.B = (int)x->shape[0]; a.HW = (int)(x->shape[2] * x->shape[3]); a.groups = groups; a.eps = eps;
+    a.gamma = gamma_dev; a.beta = beta_dev; a.silu = silu; a.y = y->data;
+    a.nsplit = groupnorm_nsplit(a.B, a.HW);
+    DevBuf part;
+    TRY(part.reserve((size_t)a.B * a.nsplit * groups * 2 * sizeof(float), false));
+    a.partial = static_cast<float*>(part.p);
+    int rc = x->dtype == MRISR_F32 ? launch_groupnorm<float>(a, st) : launch_groupnorm<bf16>(a, st);
+    if (rc) return rc;
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+    API_END
+}
+
+int mrisr_op_layernorm(const mrisr_tensor* x, const float* gamma_dev, const float* beta_dev, float eps,
+                       mrisr_tensor* y, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    MRISR_REQUIRE(x->ndim == 2 && y && y->dtype == x->dtype, "rows in/out");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)x->shape[0], C = (int)x->shape[1];
+    return x->dtype == MRISR_F32 ? launch_layernorm<float>(x->data, y->data, gamma_dev, beta_dev, M, C, eps, st)
+                                 : launch_layernorm<bf16>(x->data, y->data, gamma_dev, beta_dev, M, C, eps, st);
+    API_END
+}
+
+int mrisr_op_attention(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, int heads, int flash,
+                       mrisr_tensor* out, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(q));
+    TRY(gemm_prepare());
+    MRISR_REQUIRE(q->ndim == 3 && k && v && out && k->dtype == q->dtype && v->dtype == q->dtype && out->dtype == q->dtype,
+                  "q,k,v,out: [B,N,C] same dtype");
+    return q->dtype == MRISR_F32 ? op_attention_t<float>(q, k, v, heads, flash, out, (hipStream_t)stream)
+                                 : op_attention_t<bf16>(q, k, v, heads, flash, out, (hipStream_t)stream);
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// mrisr - MI355X (gfx950) kernels for the diffusion super-resolution denoiser hot path.
+// Shared declarations for the kernel translation units and the model runtime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace mrisr {
+
+// ---------------------------------------------------------------------------------------------
+// element types.  Activations/weights are stored either as bf16 ("fast") or f32 ("parity").
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2, DT_I64 = 3 };
+
+template <typename T> struct TypeTag;
+template <> struct TypeTag<float> { static constexpr int id = DT_F32; };
+template <> struct TypeTag<bf16> { static constexpr int id = DT_BF16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: kernels' launchers return hipError_t-like ints; C-ABI turns them into messages.
+// ---------------------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+#define MRISR_CHECK_HIP(expr)                                                                      \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            ::mrisr::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+#define MRISR_REQUIRE(cond, msg)                                                                   \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            ::mrisr::set_error(std::string("requirement failed: ") + #cond + " - " + (msg));       \
+            return 2;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// implicit GEMM  D[m][n] = sum_k A[m][k] * W[n][k]     (gemm.hip)
+//   A rows are either plain rows of up to two row-major matrices concatenated along k
+//   (skip-concat, LoRA rank tail) or the 3x3 im2col of an NHWC image (optionally nearest-x2
+//   up-sampled, stride 1/2, zero padded).  Both operands are K-contiguous.
+// ---------------------------------------------------------------------------------------------
+enum GemmAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GEGLU = 3 };
+enum GemmOut : int { OUT_ROWS = 0, OUT_HEADS = 1, OUT_F32 = 2 };
+
+struct GemmArgs {
+    // ---- A operand ----
+    const void* a0 = nullptr;  // [rows][lda0] elements of T
+    const void* a1 = nullptr;  // second source (channels c0..c0+c1), may be null
+    int c0 = 0, c1 = 0;        // channels (= k extent per tap) of each source
+    int lda0 = 0, lda1 = 0;    // row pitch in elements
+    int conv = 0;              // 0: plain rows, 1: 3x3 conv (pad 1)
+    int B = 0, Hin = 0, Win = 0, Hout = 0, Wout = 0, stride = 1, ups = 0;
+    // ---- W operand: [N][K] elements of T, K = taps*(c0+c1) ----
+    const void* w = nullptr;
+    int M = 0, N = 0, K = 0;
+    // ---- batching (blockIdx.z): element offsets ----
+    int batch = 1;
+    long long a_bs = 0, w_bs = 0;
+    int heads = 1;             // output offset = (z / heads) * o_bs + (z % heads) * o_hs
+    long long o_bs = 0, o_hs = 0;
+    // ---- split-K (blockIdx.y); partials go to `partial` as f32 [split][M][N] ----
+    int splitk = 1;
+    float* partial = nullptr;
+    // ---- epilogue ----
+    float alpha = 1.0f;
+    const float* bias = nullptr;    // [N] (GEGLU: interleaved like the weight rows)
+    const float* rowvec = nullptr;  // + rowvec[(m / rowvec_div) * rowvec_ld + n]   (time-embedding projection)
+    int rowvec_div = 1, rowvec_ld = 0;
+    int act = ACT_NONE;
+    const void* resid = nullptr;    // + resid[m][n] (T), pitch ldr; added after the activation
+    int ldr = 0;
+    int out_mode = OUT_ROWS;
+    void* out = nullptr;            // OUT_ROWS: T [M][ldo]; OUT_F32: float [M][ldo]
+    int ldo = 0;
+    // OUT_HEADS: column n -> section s = n / secC, head h, dim dd; row m -> (b, tok)
+    void* sec_ptr[3] = {nullptr, nullptr, nullptr};
+    int sec_tr[3] = {0, 0, 0};      // 1: store transposed [b][h][dd][tok] (V^T), else [b][h][tok][dd]
+    int secC = 0, hd = 0, dpad = 0, ntok = 0, npad = 0, nheads = 0;
+};
+
+int gemm_workspace_splitk(const GemmArgs& g);  // recommended split (1 = none)
+template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);
+template <typename T> int launch_splitk_reduce(const GemmArgs& g, hipStream_t st);
+const void* zero_page();  // >= 256 bytes of device zeros, valid after init_zero_page()
+int init_zero_page();
+int gemm_prepare();  // set launch attributes of every GEMM instantiation (call before graph capture)
+
+// ---------------------------------------------------------------------------------------------
+// normalisation (norm.hip)
+// ---------------------------------------------------------------------------------------------
+struct GroupNormArgs {
+    const void* x0 = nullptr;  // [B][HW][c0] T
+    const void* x1 = nullptr;  // [B][HW][c1] T or null (skip-concat)
+    int c0 = 0, c1 = 0;
+    int B = 0, HW = 0, groups = 32;
+    float eps = 1e-5f;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    int silu = 0;
+    void* y = nullptr;            // [B][HW][c0+c1] T
+    float* partial = nullptr;     // workspace: [B][nsplit][groups][2]
+    int nsplit = 1;
+};
+int groupnorm_nsplit(int B, int HW);
+template <typename T> int launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
+template <typename T>
+int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C, float eps,
+                     hipStream_t st);
+// in-place row softmax over the first nk columns of f32 rows of pitch ld; writes P as T into `p` (pitch ldp),
+// zero-filling columns nk..ldp-1
+template <typename T>
+int launch_softmax_rows(const float* s, int ld, void* p, int ldp, long long rows, int nk, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// attention (attn.hip): flash-style, head-major operands written by the QKV GEMM epilogue
+//   q  [B*H][nq ][dpad]   k [B*H][nkpad][dpad]   vt [B*H][dpad][nkpad]   -> out [B][nq][H*hd]
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const void* q = nullptr;
+    const void* k = nullptr;
+    const void* vt = nullptr;
+    void* out = nullptr;
+    int B = 0, H = 0, nq = 0, nk = 0, nkpad = 0, hd = 0, dpad = 0;
+    float scale = 1.0f;
+};
+int launch_attention_bf16(const AttnArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// small kernels (misc.hip)
+// ---------------------------------------------------------------------------------------------
+// y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ),  x,y f32, W of type T.  rows <= 64.
+template <typename T>
+int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, float* y, int ldy, int rows, int N,
+                     int K, int silu_in, hipStream_t st);
+// sinusoidal timestep embedding [rows][dim] = [cos | sin], t from device int64 (scalar broadcast or [rows])
+int launch_timestep_embedding(const long long* t, int t_is_scalar, float* out, int rows, int dim, hipStream_t st);
+// direct NHWC conv for tiny channel counts (conv_in, conv_out, ControlNet condition embedding)
+struct DirectConvArgs {
+    const void* x = nullptr;   // [B][Hin][Win][Cin] T
+    const void* w = nullptr;   // [Cout][ks*ks*Cin] T
+    const float* bias = nullptr;
+    void* y = nullptr;         // [B][Hout][Wout][Cout] T
+    int B = 0, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, Cout = 0, ks = 3, stride = 1, pad = 1, act = 0;
+    const void* add = nullptr; // + add[m][n] (T), same shape as y
+};
+template <typename T> int launch_direct_conv(const DirectConvArgs& a, hipStream_t st);
+// layout / dtype conversion at the boundary.  src dtype is a DType id.
+template <typename T>
+int launch_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, hipStream_t st);
+template <typename T>
+int launch_nhwc_to_nchw(const void* src, void* dst, int dst_dtype, int B, int C, int H, int W, float scale,
+                        hipStream_t st);
+template <typename T> int launch_add_inplace(void* x, const void* y, long long n, hipStream_t st);
+template <typename T> int launch_pixel_unshuffle_nchw(const void* src, int src_dtype, void* dst, int B, int C, int H,
+                                                      int W, int r, hipStream_t st);
+// generic row copy/cast used by the weight packers:
+//   dst[(row_map(r))][col_off + c] = scale * src[r][c]      src f32, dst T
+//   row_map: 0 identity (+row_off), 1 GEGLU interleave (u/g blocks of 16; src has 2*half rows)
+template <typename T>
+int launch_pack_rows(const float* src, int rows, int cols, void* dst, int ld_dst, int row_off, int col_off,
+                     int row_map, int half, float scale, hipStream_t st);
+// conv weight [Cout][Cin][3][3] f32 -> [Cout][ky][kx][Cin] T
+template <typename T>
+int launch_pack_conv3x3(const float* src, void* dst, int Cout, int Cin, int ks, hipStream_t st);
+int launch_pack_bias_geglu(const float* src, float* dst, int half, hipStream_t st);
+template <typename T> int launch_fill_zero(void* p, long long n, hipStream_t st);
+// sampler steps (f32 state, NCHW like the reference's latents)
+//   ddim: x = cx*x + ce*eps;   coefficients read from a device table indexed by *step_idx
+int launch_ddim_step(float* x, const float* eps, const float* coef_table, const int* step_idx, long long n,
+                     hipStream_t st);
+//   res-srdiff reverse step (reference res_srdiff.py:84-96): coef row = {sqrt_at, sqrt_1mat, sqrt_ap, sigma}
+int launch_resshift_step(float* x, const float* eps, const float* lr, const float* noise, const float* coef_table,
+                         const int* step_idx, long long n, hipStream_t st);
+int launch_advance_step(int* step_idx, hipStream_t st);
+//   forward shift (reference res_srdiff.py:7-25): per-sample alpha from table[t[b]]
+int launch_resshift_forward(const float* hr, const float* lr, const float* noise, const float* alphas_cumprod,
+                            const long long* t, int t_is_scalar, float* out, int B, long long per_sample,
+                            hipStream_t st);
+
+}  // namespace mrisr

@@ -1,0 +1,482 @@
+// Implicit GEMM on the CDNA4 matrix cores:  D[m][n] = sum_k A[m][k] * W[n][k]
+//
+//  * one kernel serves every dense contraction of the denoiser: 3x3 convolutions (im2col gathered on the
+//    fly from NHWC activations: stride 1/2, optional nearest-x2 up-sampling, zero padding, skip-concat of
+//    two sources), 1x1 convolutions / linears (plain rows, optional second K-source = the LoRA rank tail
+//    or a concat), and the batched Q.K^T / P.V products of the f32 parity attention;
+//  * both operands are K-contiguous, staged global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4)
+//    into 128-byte rows whose 16-byte chunks are XOR-swizzled on the SOURCE side (chunk ^= row & 7) so that
+//    the ds_read_b128 fragment reads are bank-conflict free; rows that fall outside the matrix or in the
+//    conv's zero padding read a device zero page instead;
+//  * MFMA is issued with the weight rows as the first operand, so a lane ends up with 4 consecutive
+//    output channels n of one output row m: epilogue math (bias, time-embedding row vector, activation,
+//    GEGLU gate, residual) is per-lane and the store is one 8/16-byte word per (m, 4n);
+//  * bf16 path: v_mfma_f32_16x16x32_bf16;  f32 parity path: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
+#include "common.h"
+
+namespace mrisr {
+
+static void* g_zero_page = nullptr;
+const void* zero_page() { return g_zero_page; }
+int init_zero_page() {
+    if (g_zero_page) return 0;
+    MRISR_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
+    MRISR_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+    return 0;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// ---- epilogue for 4 consecutive output channels n0..n0+3 of output row m (shared with split-K reduce) ----
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<bf16>(bf16* p, const float* v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float* v);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float* v) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load4<bf16>(const bf16* p, float* v) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+// v: accumulated values (already summed over K) for columns n0..n0+3 (GEGLU: u values; gate in vg).
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg) {
+    const float alpha = g.alpha;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.act == ACT_GEGLU) {
+        // weight rows are interleaved in blocks of 16: [u0..u15 | g0..g15 | u16.. ]; n0 indexes the u block
+        // in the interleaved space, the gate block sits 16 columns later; output column = compacted index.
+        float bu[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
+        if (g.bias) {
+            load4<float>(g.bias + n0, bu);
+            load4<float>(g.bias + n0 + 16, bg);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] * alpha + bu[r]) * gelu_erf_f(vg[r] * alpha + bg[r]);
+        const int nc = (n0 >> 5) * 16 + (n0 & 15);
+        T* o = reinterpret_cast<T*>(g.out) + (size_t)m * g.ldo + nc;
+        store4<T>(o, v);
+        return;
+    }
+    if (g.bias) load4<float>(g.bias + n0, b4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] * alpha + b4[r];
+    if (g.rowvec) {
+        float t4[4];
+        load4<float>(g.rowvec + (size_t)(m / g.rowvec_div) * g.rowvec_ld + n0, t4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t4[r];
+    }
+    if (g.act == ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (g.act == ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    }
+    const size_t zoff = (size_t)(z / g.heads) * g.o_bs + (size_t)(z % g.heads) * g.o_hs;
+    if (g.resid) {
+        float r4[4];
+        load4<T>(reinterpret_cast<const T*>(g.resid) + zoff + (size_t)m * g.ldr + n0, r4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += r4[r];
+    }
+    if (g.out_mode == OUT_ROWS) {
+        store4<T>(reinterpret_cast<T*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
+    } else if (g.out_mode == OUT_F32) {
+        store4<float>(reinterpret_cast<float*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
+    } else {  // OUT_HEADS
+        const int s = n0 / g.secC;
+        const int c = n0 - s * g.secC;
+        const int h = c / g.hd;
+        const int dd = c - h * g.hd;
+        const int b = m / g.ntok;
+        const int tok = m - b * g.ntok;
+        T* base = reinterpret_cast<T*>(s == 0 ? g.sec_ptr[0] : (s == 1 ? g.sec_ptr[1] : g.sec_ptr[2]));
+        const int tr = (s == 0 ? g.sec_tr[0] : (s == 1 ? g.sec_tr[1] : g.sec_tr[2]));
+        const size_t bh = (size_t)b * g.nheads + h;
+        if (!tr) {
+            store4<T>(base + (bh * g.npad + tok) * g.dpad + dd, v);
+        } else {
+            T* o = base + (bh * g.dpad + dd) * g.npad + tok;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(size_t)r * g.npad] = from_f32<T>(v[r]);
+        }
+    }
+}
+
+// ---- MFMA wrappers -------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+__device__ __forceinline__ void mma(f32x4& acc, const bf16x8& w, const bf16x8& a) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, const f32x4& w, const f32x4& a) {
+    // lane group g supplies k = 4g+j at step j: a permutation of the 16 k's shared by both operands
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], a[j], acc, 0, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char* __restrict__ zero) {
+    constexpr int EB = sizeof(T);
+    constexpr int CH = 16 / EB;   // elements per 16-byte chunk
+    constexpr int BK = 8 * CH;    // elements per 128-byte LDS row
+    constexpr int A_IT = BM / 32, W_IT = BN / 32;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int MF = WTM / 16, NF = WTN / 16;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WGM * WGN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z;
+    const int split = blockIdx.y;
+
+    // ---- tile decode with an XCD-contiguous remap (blocks b, b+8, ... share an XCD/L2) ----
+    const int ntn = (g.N + BN - 1) / BN;
+    const int ntm = (g.M + BM - 1) / BM;
+    const int nblk = ntn * ntm;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = logical % ntn, tm = logical / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const T* a0 = reinterpret_cast<const T*>(g.a0) + (size_t)z * g.a_bs;
+    const T* a1 = reinterpret_cast<const T*>(g.a1);
+    const T* w = reinterpret_cast<const T*>(g.w) + (size_t)z * g.w_bs;
+
+    // ---- per-thread loader geometry ----
+    const int lrow = tid >> 3, pch = tid & 7;
+    const T* wsrc[W_IT];
+    bool wok[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int row = it * 32 + lrow;
+        const int n = n0 + row;
+        const int c = pch ^ (row & 7);
+        wok[it] = n < g.N;
+        wsrc[it] = w + (size_t)n * g.K + c * CH;
+    }
+    // plain mode: row pointers; conv mode: output pixel coordinates
+    const T* asrc0[A_IT];
+    const T* asrc1[A_IT];
+    int ab[A_IT], ay[A_IT], ax[A_IT];
+    bool aok[A_IT];
+    int acoff[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = it * 32 + lrow;
+        const int m = m0 + row;
+        const int c = pch ^ (row & 7);
+        aok[it] = m < g.M;
+        acoff[it] = c * CH;
+        if (!g.conv) {
+            asrc0[it] = a0 + (size_t)m * g.lda0 + c * CH;
+            asrc1[it] = a1 ? a1 + (size_t)m * g.lda1 + c * CH : nullptr;
+            ab[it] = ay[it] = ax[it] = 0;
+        } else {
+            const int hw = g.Hout * g.Wout;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / g.Wout;
+            ab[it] = b;
+            ay[it] = oy * g.stride - 1;
+            ax[it] = (rem - oy * g.Wout) * g.stride - 1;
+            asrc0[it] = asrc1[it] = nullptr;
+        }
+    }
+
+    // ---- K range of this split ----
+    const int nkt = g.K / BK;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int kt_beg = split * per;
+    const int kt_end = min(nkt, kt_beg + per);
+    const int Ct = g.c0 + g.c1;
+    // conv k-walk state (uniform)
+    int tap = 0, cc = 0;
+    if (g.conv) {
+        const int k0 = kt_beg * BK;
+        tap = k0 / Ct;
+        cc = k0 - tap * Ct;
+    }
+    const int Hc = g.Hin << g.ups, Wc = g.Win << g.ups;
+
+    auto stage = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE;
+        const int k0 = kt * BK;
+        // W tile
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const void* src = wok[it] ? (const void*)(wsrc[it] + k0) : (const void*)zero;
+            glds16(src, sb + BM * 128 + (it * 256 + wave * 64) * 16);
+        }
+        if (!g.conv) {
+            const bool second = k0 >= g.c0;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const void* src = zero;
+                if (aok[it]) src = second ? (const void*)(asrc1[it] + (k0 - g.c0)) : (const void*)(asrc0[it] + k0);
+                glds16(src, sb + (it * 256 + wave * 64) * 16);
+            }
+        } else {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const bool second = cc >= g.c0;
+            const T* base = second ? a1 : a0;
+            const int ld = second ? g.lda1 : g.lda0;
+            const int ch = second ? cc - g.c0 : cc;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int iy = ay[it] + ky, ix = ax[it] + kx;
+                const void* src = zero;
+                if (aok[it] && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) {
+                    const size_t pix = ((size_t)ab[it] * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups);
+                    src = base + pix * ld + ch + acoff[it];
+                }
+                glds16(src, sb + (it * 256 + wave * 64) * 16);
+            }
+            cc += BK;
+            if (cc >= Ct) { cc = 0; ++tap; }
+        }
+    };
+
+    // ---- accumulators ----
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm0 = (wave / WGN) * WTM, wn0 = (wave % WGN) * WTN;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    typedef typename Frag<T>::type frag_t;
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE;
+        const char* sw = sa + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int phys = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            frag_t wf[NF], af[MF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                wf[i] = *reinterpret_cast<const frag_t*>(sw + (wn0 + i * 16 + fr) * 128 + phys);
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+                af[j] = *reinterpret_cast<const frag_t*>(sa + (wm0 + j * 16 + fr) * 128 + phys);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) mma(acc[i][j], wf[i], af[j]);
+        }
+    };
+
+    if (kt_beg < kt_end) {
+        stage(kt_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue ----
+    if (g.splitk > 1) {
+        float* part = g.partial + ((size_t)z * g.splitk + split) * (size_t)g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wm0 + j * 16 + fr;
+                const int n = n0 + wn0 + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4<float>(part + (size_t)m * g.N + n, v);
+                }
+            }
+        return;
+    }
+    if (g.act == ACT_GEGLU) {
+#pragma unroll
+        for (int i = 0; i < NF; i += 2)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wm0 + j * 16 + fr;
+                const int n = n0 + wn0 + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    float vg[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
+                    epilogue4<T>(g, z, m, n, v, vg);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wm0 + j * 16 + fr;
+            const int n = n0 + wn0 + i * 16 + fg * 4;
+            if (m < g.M && n < g.N) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue4<T>(g, z, m, n, v, nullptr);
+            }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
+    const int nq = g.N >> 2;
+    const long long total = (long long)g.M * nq;
+    const int z = blockIdx.z;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / nq);
+        const int n = (int)(i - (long long)m * nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* p = g.partial + (size_t)z * g.splitk * (size_t)g.M * g.N + (size_t)m * g.N + n;
+        for (int s = 0; s < g.splitk; ++s) {
+            float t[4];
+            load4<float>(p + (size_t)s * g.M * g.N, t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += t[r];
+        }
+        epilogue4<T>(g, z, m, n, v, nullptr);
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int prepare_cfg() {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        auto kern = gemm_kernel<T, BM, BN, WGM, WGN>;
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    return 0;
+}
+template <typename T>
+static int prepare_all() {
+    if (prepare_cfg<T, 128, 128, 2, 2>()) return 1;
+    if (prepare_cfg<T, 256, 64, 4, 1>()) return 1;
+    if (prepare_cfg<T, 128, 64, 2, 2>()) return 1;
+    if (prepare_cfg<T, 64, 64, 2, 2>()) return 1;
+    return 0;
+}
+// Raise the dynamic-LDS limit of every GEMM instantiation up front (never inside a stream capture).
+int gemm_prepare() {
+    if (init_zero_page()) return 1;
+    if (prepare_all<float>()) return 1;
+    return prepare_all<bf16>();
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = gemm_kernel<T, BM, BN, WGM, WGN>;
+    if (prepare_cfg<T, BM, BN, WGM, WGN>()) return 1;
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    dim3 grid(ntn * ntm, g.splitk, g.batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g, (const char*)zero_page());
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int g_force_tile = 0;  // test hook: 0 auto, 1..4 fixed config
+extern "C" void mrisr_debug_force_tile(int t) { g_force_tile = t; }
+
+static int pick_tile(const GemmArgs& g) {
+    if (g_force_tile) return g_force_tile;
+    if (g.act == ACT_GEGLU) return 1;                 // needs NF even and >= 2 per wave: 128x128 (NF=4)
+    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
+    if (g.N % 128 != 0 && g.N % 64 == 0 && g.M >= 4096) return 2;   // e.g. N = 320: 256x64 tiles, no N waste
+    if (g.N <= 64) return (g.M >= 4096) ? 2 : 4;
+    if (t128 < 128) return 4;                         // tiny problems: 64x64 tiles for more blocks
+    return 1;
+}
+
+int gemm_workspace_splitk(const GemmArgs& g) {
+    // split K when the 128x128 tiling leaves most of the 256 CUs idle and K is deep
+    const int bk = 64;
+    const long long tiles = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    const int nkt = g.K / bk;
+    if (g.act == ACT_GEGLU) return 1;
+    if (tiles >= 192 || nkt < 16) return 1;
+    int s = (int)((384 + tiles - 1) / tiles);
+    if (s > nkt / 8) s = nkt / 8;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+template <typename T>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    MRISR_REQUIRE(g.K % BK == 0, "K must be a multiple of the 128-byte K tile");
+    MRISR_REQUIRE(g.N % 4 == 0, "N must be a multiple of 4");
+    MRISR_REQUIRE(g.c0 % BK == 0 && g.c1 % BK == 0, "channel extents must be multiples of the K tile");
+    MRISR_REQUIRE(g.splitk == 1 || g.partial != nullptr, "split-K needs a partial buffer");
+    MRISR_REQUIRE(g.splitk == 1 || g.act != ACT_GEGLU, "GEGLU epilogue cannot be split");
+    MRISR_REQUIRE(zero_page() != nullptr, "zero page not initialised");
+    if (g.conv) MRISR_REQUIRE(g.K == 9 * (g.c0 + g.c1), "conv K");
+    else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
+    int rc;
+    switch (pick_tile(g)) {
+        case 2: rc = launch_cfg<T, 256, 64, 4, 1>(g, st); break;
+        case 3: rc = launch_cfg<T, 128, 64, 2, 2>(g, st); break;
+        case 4: rc = launch_cfg<T, 64, 64, 2, 2>(g, st); break;
+        default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
+    }
+    if (rc) return rc;
+    if (g.splitk > 1) return launch_splitk_reduce<T>(g, st);
+    return 0;
+}
+
+template <typename T>
+int launch_splitk_reduce(const GemmArgs& g, hipStream_t st) {
+    const long long total = (long long)g.M * (g.N / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks, 1, g.batch), dim3(256), 0, st, g);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template int launch_gemm<float>(const GemmArgs&, hipStream_t);
+template int launch_gemm<bf16>(const GemmArgs&, hipStream_t);
+template int launch_splitk_reduce<float>(const GemmArgs&, hipStream_t);
+template int launch_splitk_reduce<bf16>(const GemmArgs&, hipStream_t);
+
+}  // namespace mrisr

@@ -1,0 +1,387 @@
+// Small / bandwidth-bound kernels: time-embedding GEMV, direct convolutions for tiny channel counts,
+// NCHW<->NHWC boundary conversion, weight packers, and the fused sampler steps.
+#include "common.h"
+
+namespace mrisr {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[b][n] = sum_k act(x[b][k]) W[n][k] + bias[n];  one wave per output column n, RB rows at a time.
+// Weight-streaming (each W row read once, 16 B per lane); x is tiny and L1/L2 resident.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int RB>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ x, int ldx,
+                                                        const T* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int ldy, int rows, int N, int K,
+                                                        int silu_in) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    for (int r0 = 0; r0 < rows; r0 += RB) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int k = lane * VE; k < K; k += 64 * VE) {
+            float wv[VE];
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(w + (size_t)n * K + k);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) wv[e] = (float)t[e];
+            } else {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(w + (size_t)n * K + k);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) wv[e] = t[e];
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (r0 + r < rows) {
+                    const float* xr = x + (size_t)(r0 + r) * ldx + k;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        float xv = xr[e];
+                        if (silu_in) xv = silu_f(xv);
+                        acc[r] += xv * wv[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float s = wsum(acc[r]);
+            if (lane == 0 && r0 + r < rows) y[(size_t)(r0 + r) * ldy + n] = s + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+
+template <typename T>
+int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, float* y, int ldy, int rows, int N,
+                     int K, int silu_in, hipStream_t st) {
+    MRISR_REQUIRE(K % (16 / (int)sizeof(T)) == 0, "gemv K alignment");
+    const dim3 grid((N + 3) / 4);
+    if (rows <= 1)
+        hipLaunchKernelGGL((gemv_rows_kernel<T, 1>), grid, dim3(256), 0, st, x, ldx, reinterpret_cast<const T*>(w), bias,
+                           y, ldy, rows, N, K, silu_in);
+    else
+        hipLaunchKernelGGL((gemv_rows_kernel<T, 8>), grid, dim3(256), 0, st, x, ldx, reinterpret_cast<const T*>(w), bias,
+                           y, ldy, rows, N, K, silu_in);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void timestep_embedding_kernel(const long long* __restrict__ t, int t_is_scalar, float* __restrict__ out,
+                                          int rows, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * half) return;
+    const int r = i / half, j = i - r * half;
+    const float tv = (float)(t_is_scalar ? t[0] : t[r]);
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
+    const float ang = tv * freq;
+    out[(size_t)r * dim + j] = cosf(ang);
+    out[(size_t)r * dim + half + j] = sinf(ang);
+}
+int launch_timestep_embedding(const long long* t, int t_is_scalar, float* out, int rows, int dim, hipStream_t st) {
+    const int n = rows * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, t_is_scalar, out, rows, dim);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct convolution, one thread per (output pixel, output channel); f32 accumulate.
+// Only for the few layers whose channel counts are far below one MFMA K tile.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void direct_conv_kernel(const DirectConvArgs a) {
+    const long long total = (long long)a.B * a.Hout * a.Wout * a.Cout;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* w = reinterpret_cast<const T*>(a.w);
+    T* y = reinterpret_cast<T*>(a.y);
+    const int Kt = a.ks * a.ks * a.Cin;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i % a.Cout);
+        const long long m = i / a.Cout;
+        const int ox = (int)(m % a.Wout);
+        const int oy = (int)((m / a.Wout) % a.Hout);
+        const int b = (int)(m / ((long long)a.Wout * a.Hout));
+        float acc = a.bias ? a.bias[n] : 0.f;
+        for (int ky = 0; ky < a.ks; ++ky) {
+            const int iy = oy * a.stride + ky - a.pad;
+            if (iy < 0 || iy >= a.Hin) continue;
+            for (int kx = 0; kx < a.ks; ++kx) {
+                const int ix = ox * a.stride + kx - a.pad;
+                if (ix < 0 || ix >= a.Win) continue;
+                const T* xp = x + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin;
+                const T* wp = w + (size_t)n * Kt + (ky * a.ks + kx) * a.Cin;
+                for (int c = 0; c < a.Cin; ++c) acc += to_f32(xp[c]) * to_f32(wp[c]);
+            }
+        }
+        if (a.act == ACT_SILU) acc = silu_f(acc);
+        else if (a.act == ACT_RELU) acc = fmaxf(acc, 0.f);
+        if (a.add) acc += to_f32(reinterpret_cast<const T*>(a.add)[i]);
+        y[i] = from_f32<T>(acc);
+    }
+}
+template <typename T>
+int launch_direct_conv(const DirectConvArgs& a, hipStream_t st) {
+    const long long total = (long long)a.B * a.Hout * a.Wout * a.Cout;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65535 * 4) blocks = 65535 * 4;
+    hipLaunchKernelGGL(direct_conv_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv_out-style reduction: few output channels (<= 8), deep K: one wave per output pixel.
+// (used through launch_direct_conv's sibling below when Cout <= 8 and Cin % 64 == 0)
+
+// ------------------------------------------------------------------------------------------------
+// boundary layout/dtype conversion
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float load_any(const void* p, int dt, size_t i) {
+    switch (dt) {
+        case DT_F32: return reinterpret_cast<const float*>(p)[i];
+        case DT_BF16: return (float)reinterpret_cast<const bf16*>(p)[i];
+        default: return (float)reinterpret_cast<const _Float16*>(p)[i];
+    }
+}
+__device__ __forceinline__ void store_any(void* p, int dt, size_t i, float v) {
+    switch (dt) {
+        case DT_F32: reinterpret_cast<float*>(p)[i] = v; break;
+        case DT_BF16: reinterpret_cast<bf16*>(p)[i] = (bf16)v; break;
+        default: reinterpret_cast<_Float16*>(p)[i] = (_Float16)v; break;
+    }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const void* src, int sdt, T* dst, int B, int C, int H, int W) {
+    const long long total = (long long)B * C * H * W;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long p = i / C;  // b*H*W + y*W + x
+        const long long hw = (long long)H * W;
+        const long long b = p / hw, r = p - b * hw;
+        dst[i] = from_f32<T>(load_any(src, sdt, (size_t)((b * C + c) * hw + r)));
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, void* dst, int ddt, int B, int C, int H, int W, float scale) {
+    const long long total = (long long)B * C * H * W;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        // i indexes the NCHW destination (coalesced writes)
+        const long long hw = (long long)H * W;
+        const long long r = i % hw;
+        const long long bc = i / hw;
+        const long long c = bc % C, b = bc / C;
+        store_any(dst, ddt, (size_t)i, scale * to_f32(src[(size_t)((b * hw + r) * C + c)]));
+    }
+}
+static inline unsigned nblocks(long long total) {
+    long long b = (total + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+template <typename T>
+int launch_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(nblocks((long long)B * C * H * W)), dim3(256), 0, st, src,
+                       src_dtype, reinterpret_cast<T*>(dst), B, C, H, W);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <typename T>
+int launch_nhwc_to_nchw(const void* src, void* dst, int dst_dtype, int B, int C, int H, int W, float scale,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(nblocks((long long)B * C * H * W)), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(src), dst, dst_dtype, B, C, H, W, scale);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ void add_inplace_kernel(T* x, const T* y, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        x[i] = from_f32<T>(to_f32(x[i]) + to_f32(y[i]));
+}
+template <typename T>
+int launch_add_inplace(void* x, const void* y, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(add_inplace_kernel<T>, dim3(nblocks(n)), dim3(256), 0, st, reinterpret_cast<T*>(x),
+                       reinterpret_cast<const T*>(y), n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// PixelUnshuffle(r) of an NCHW image straight into NHWC:  out[b][y][x][c*r*r + dy*r + dx] = in[b][c][y*r+dy][x*r+dx]
+template <typename T>
+__global__ void pixel_unshuffle_kernel(const void* src, int sdt, T* dst, int B, int C, int H, int W, int r) {
+    const int Ho = H / r, Wo = W / r, Co = C * r * r;
+    const long long total = (long long)B * Ho * Wo * Co;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Co);
+        const long long p = i / Co;
+        const int x = (int)(p % Wo);
+        const int y = (int)((p / Wo) % Ho);
+        const int b = (int)(p / ((long long)Wo * Ho));
+        const int c = co / (r * r), dy = (co / r) % r, dx = co % r;
+        dst[i] = from_f32<T>(load_any(src, sdt, (((size_t)b * C + c) * H + (y * r + dy)) * W + (x * r + dx)));
+    }
+}
+template <typename T>
+int launch_pixel_unshuffle_nchw(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, int r,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(pixel_unshuffle_kernel<T>, dim3(nblocks((long long)B * C * H * W)), dim3(256), 0, st, src,
+                       src_dtype, reinterpret_cast<T*>(dst), B, C, H, W, r);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packers (load time)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_rows_kernel(const float* src, int rows, int cols, T* dst, int ld_dst, int row_off, int col_off,
+                                 int row_map, int half, float scale) {
+    const long long total = (long long)rows * cols;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        int dr = r + row_off;
+        if (row_map == 1) {  // GEGLU: src rows [0,half) = u, [half,2half) = gate -> blocks of 16 interleaved
+            const int isg = r >= half;
+            const int j = isg ? r - half : r;
+            dr = (j >> 4) * 32 + (j & 15) + (isg ? 16 : 0) + row_off;
+        }
+        dst[(size_t)dr * ld_dst + col_off + c] = from_f32<T>(scale * src[i]);
+    }
+}
+template <typename T>
+int launch_pack_rows(const float* src, int rows, int cols, void* dst, int ld_dst, int row_off, int col_off,
+                     int row_map, int half, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(pack_rows_kernel<T>, dim3(nblocks((long long)rows * cols)), dim3(256), 0, st, src, rows, cols,
+                       reinterpret_cast<T*>(dst), ld_dst, row_off, col_off, row_map, half, scale);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <typename T>
+__global__ void pack_conv_kernel(const float* src, T* dst, int Cout, int Cin, int ks) {
+    const long long total = (long long)Cout * Cin * ks * ks;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        // i indexes dst [Cout][ky][kx][Cin]
+        const int c = (int)(i % Cin);
+        const long long t = i / Cin;
+        const int tap = (int)(t % (ks * ks));
+        const int n = (int)(t / (ks * ks));
+        dst[i] = from_f32<T>(src[((size_t)n * Cin + c) * ks * ks + tap]);
+    }
+}
+template <typename T>
+int launch_pack_conv3x3(const float* src, void* dst, int Cout, int Cin, int ks, hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv_kernel<T>, dim3(nblocks((long long)Cout * Cin * ks * ks)), dim3(256), 0, st, src,
+                       reinterpret_cast<T*>(dst), Cout, Cin, ks);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void pack_bias_geglu_kernel(const float* src, float* dst, int half) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * half) return;
+    const int isg = r >= half;
+    const int j = isg ? r - half : r;
+    dst[(j >> 4) * 32 + (j & 15) + (isg ? 16 : 0)] = src[r];
+}
+int launch_pack_bias_geglu(const float* src, float* dst, int half, hipStream_t st) {
+    hipLaunchKernelGGL(pack_bias_geglu_kernel, dim3((2 * half + 255) / 256), dim3(256), 0, st, src, dst, half);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <typename T>
+__global__ void fill_zero_kernel(T* p, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = from_f32<T>(0.f);
+}
+template <typename T>
+int launch_fill_zero(void* p, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(fill_zero_kernel<T>, dim3(nblocks(n)), dim3(256), 0, st, reinterpret_cast<T*>(p), n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler steps: one fused elementwise kernel per step, coefficients from a device table indexed by a
+// device-resident step counter (so one captured hipGraph replays for every step, and the reference's
+// host sync on `prev_t > 0` (res_srdiff.py:92) disappears: sigma is simply 0 on the last row).
+// ------------------------------------------------------------------------------------------------
+__global__ void ddim_step_kernel(float* x, const float* eps, const float* coef, const int* step, long long n) {
+    const int s = *step;
+    const float cx = coef[2 * s], ce = coef[2 * s + 1];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        x[i] = cx * x[i] + ce * eps[i];
+}
+int launch_ddim_step(float* x, const float* eps, const float* coef_table, const int* step_idx, long long n,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(nblocks(n)), dim3(256), 0, st, x, eps, coef_table, step_idx, n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void resshift_step_kernel(float* x, const float* eps, const float* lr, const float* noise_base,
+                                     const float* coef, const int* step, long long n) {
+    const int s = *step;
+    const float* noise = noise_base ? noise_base + (size_t)s * n : nullptr;  // one [n] slab per stochastic step
+    // row = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sigma}
+    const float sat = coef[4 * s], s1mat = coef[4 * s + 1], sap = coef[4 * s + 2], sig = coef[4 * s + 3];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float l = lr[i];
+        const float x0 = (x[i] - (1.f - sat) * l - s1mat * eps[i]) / sat;
+        float v = sap * x0 + (1.f - sap) * l;
+        if (sig != 0.f && noise) v += sig * noise[i];
+        x[i] = v;
+    }
+}
+int launch_resshift_step(float* x, const float* eps, const float* lr, const float* noise, const float* coef_table,
+                         const int* step_idx, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(resshift_step_kernel, dim3(nblocks(n)), dim3(256), 0, st, x, eps, lr, noise, coef_table,
+                       step_idx, n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void advance_step_kernel(int* step) { *step += 1; }
+int launch_advance_step(int* step_idx, hipStream_t st) {
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, step_idx);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void resshift_forward_kernel(const float* hr, const float* lr, const float* noise, const float* ac,
+                                        const long long* t, int t_is_scalar, float* out, int B, long long per) {
+    const long long n = (long long)B * per;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / per);
+        const float a = ac[t_is_scalar ? t[0] : t[b]];
+        const float ra = sqrtf(a);
+        out[i] = ra * hr[i] + (1.f - ra) * lr[i] + sqrtf(1.f - a) * noise[i];
+    }
+}
+int launch_resshift_forward(const float* hr, const float* lr, const float* noise, const float* alphas_cumprod,
+                            const long long* t, int t_is_scalar, float* out, int B, long long per_sample,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(resshift_forward_kernel, dim3(nblocks((long long)B * per_sample)), dim3(256), 0, st, hr, lr,
+                       noise, alphas_cumprod, t, t_is_scalar, out, B, per_sample);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+#define INST(T)                                                                                                    \
+    template int launch_gemv_rows<T>(const float*, int, const void*, const float*, float*, int, int, int, int, int, \
+                                     hipStream_t);                                                                 \
+    template int launch_direct_conv<T>(const DirectConvArgs&, hipStream_t);                                        \
+    template int launch_nchw_to_nhwc<T>(const void*, int, void*, int, int, int, int, hipStream_t);                 \
+    template int launch_nhwc_to_nchw<T>(const void*, void*, int, int, int, int, int, float, hipStream_t);          \
+    template int launch_add_inplace<T>(void*, const void*, long long, hipStream_t);                                \
+    template int launch_pixel_unshuffle_nchw<T>(const void*, int, void*, int, int, int, int, int, hipStream_t);    \
+    template int launch_pack_rows<T>(const float*, int, int, void*, int, int, int, int, int, float, hipStream_t);  \
+    template int launch_pack_conv3x3<T>(const float*, void*, int, int, int, hipStream_t);                          \
+    template int launch_fill_zero<T>(void*, long long, hipStream_t);
+INST(float)
+INST(bf16)
+
+}  // namespace mrisr

@@ -1,0 +1,92 @@
+// Model object behind the opaque mrisr_model handle (UNet2DConditionModel or ControlNetModel).
+#pragma once
+#include "runtime.h"
+
+namespace mrisr {
+
+struct ResW {
+    NormW n1, n2;
+    ConvW c1, c2;
+    bool has_sc = false;
+    LinW sc;
+    int temb_off = 0, cin = 0, cout = 0;
+};
+struct XfW {
+    int C = 0;
+    NormW norm, ln1, ln2, ln3;
+    LinW proj_in, proj_out, qkv, out1, q2, kv2, out2, ff1, ff2;
+    void* kc = nullptr;   // cached cross-attention K   [B*H][ctx_pad][dpad]
+    void* vtc = nullptr;  // cached cross-attention V^T [B*H][dpad][ctx_pad]
+};
+struct Level {
+    std::vector<ResW> res;
+    std::vector<XfW> xf;
+    bool has_down = false, has_up = false;
+    ConvW down, up;
+};
+struct HeadBuf {  // head-major q / k / v^T staging for one (tokens, channels) geometry; pads stay zero
+    int B = 0, H = 0, N = 0, hd = 0, npad = 0, dpad = 0;
+    void* q = nullptr;
+    void* k = nullptr;
+    void* vt = nullptr;
+};
+
+const char* last_error_cstr();
+
+struct Model {
+    mrisr_unet_cfg cfg{};
+    bool is_controlnet = false;
+    std::map<std::string, RawParam> raw;
+    float lora_scale = 1.0f;
+    bool finalized = false;
+    std::vector<std::unique_ptr<DevBuf>> packed;
+
+    // packed modules
+    ConvW conv_in, conv_out;
+    NormW norm_out;
+    LinW te1, te2, tproj;
+    std::vector<std::string> temb_mods;
+    int tproj_total = 0;
+    std::vector<Level> down, up;
+    ResW mid_r0, mid_r1;
+    XfW mid_xf;
+    std::vector<ConvW> ce;  // ControlNet condition embedding
+    std::vector<int> ce_stride;
+    std::vector<LinW> cn_down;
+    LinW cn_mid;
+
+    // workspace (planned per input geometry)
+    Arena arena;
+    DevBuf persist;
+    std::string ws_key;
+    int ws_B = 0, ws_h = 0, ws_w = 0, ctx_len = 0, ctx_pad = 0;
+    std::vector<HeadBuf> heads;
+    void* ctx_rows = nullptr;
+    void* cond_emb = nullptr;
+    size_t cond_emb_bytes = 0;
+    bool ctx_valid = false, cond_valid = false;
+    // per-forward state
+    float* tproj_out = nullptr;
+    int t_scalar = 1;
+
+    int set_param(const char* key, const float* data, const int64_t* shape, int ndim, int is_device);
+    int64_t num_params() const;
+    const RawParam* find(const std::string& k) const;
+    void* new_packed(size_t bytes, bool zero);
+    int finalize(hipStream_t st);
+    int num_skips() const;
+    int skip_shape(int k, int B, int h, int w, int64_t shape[4]) const;
+    const HeadBuf& head_buf(int N, int C) const;
+    const HeadBuf& head_buf_for_C(int C) const;
+    int ensure_workspace(int B, int h, int w, int L, hipStream_t st);
+    int forward_unet(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                     const mrisr_tensor* down_res, int n_down, const mrisr_tensor* mid_res,
+                     const mrisr_tensor* intrablock, int n_intra, mrisr_tensor* out, hipStream_t st);
+    int forward_controlnet(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                           const mrisr_tensor* cond, float scale, mrisr_tensor* down_out, int n_down,
+                           mrisr_tensor* mid_out, hipStream_t st);
+    int set_context(const mrisr_tensor* ehs, int B, int h, int w, hipStream_t st);
+    int set_cond(const mrisr_tensor* cond, int L, hipStream_t st);
+};
+
+}  // namespace mrisr

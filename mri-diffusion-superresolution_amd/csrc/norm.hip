@@ -1,0 +1,292 @@
+// GroupNorm(+SiLU) over NHWC activations (with the skip-concat of two sources folded into the read),
+// LayerNorm over token rows, and the row softmax of the f32 parity attention.  All HBM-bound: 16-byte
+// vector accesses, f32 statistics, deterministic two-stage reductions (no float atomics).
+#include "common.h"
+
+namespace mrisr {
+
+template <typename T> struct Vec;  // 16-byte vector of T
+template <> struct Vec<bf16> {
+    static constexpr int N = 8;
+    typedef bf16x8 type;
+};
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    typedef f32x4 type;
+};
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm stage 1: per (sample, row-split) partial sums per group.
+//   block = (slots = C/VE/VPT) x RL threads; a thread owns VPT 16-byte channel vectors of every
+//   RL-th row of its split, so its accumulators are per-channel; the block then folds rows and
+//   channels-of-a-group through LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormArgs a, int slots, int RL) {
+    constexpr int VE = Vec<T>::N;
+    typedef typename Vec<T>::type vec_t;
+    extern __shared__ float sm[];  // [2][RL][C]
+    const int C = a.c0 + a.c1;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int slot = tid % slots, rl = tid / slots;
+    const int rows_per = (a.HW + a.nsplit - 1) / a.nsplit;
+    const int r_beg = sp * rows_per, r_end = min(a.HW, r_beg + rows_per);
+    float s1[VPT][VE], s2[VPT][VE];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s1[v][e] = s2[v][e] = 0.f;
+    if (rl < RL) {
+        for (int r = r_beg + rl; r < r_end; r += RL) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int ch = (slot * VPT + v) * VE;
+                const T* src = ch < a.c0
+                                   ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                                   : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+                const vec_t x = *reinterpret_cast<const vec_t*>(src);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float f = (float)x[e];
+                    s1[v][e] += f;
+                    s2[v][e] += f * f;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int ch = (slot * VPT + v) * VE + e;
+                sm[(size_t)rl * C + ch] = s1[v][e];
+                sm[(size_t)(RL + rl) * C + ch] = s2[v][e];
+            }
+    }
+    __syncthreads();
+    const int Cg = C / a.groups;
+    if (tid < 2 * a.groups) {
+        const int gq = tid % a.groups, which = tid / a.groups;
+        double acc = 0.0;
+        for (int r = 0; r < RL; ++r) {
+            const float* row = sm + (size_t)(which * RL + r) * C + gq * Cg;
+            float t = 0.f;
+            for (int c = 0; c < Cg; ++c) t += row[c];
+            acc += (double)t;
+        }
+        a.partial[(((size_t)b * a.nsplit + sp) * a.groups + gq) * 2 + which] = (float)acc;
+    }
+}
+
+// GroupNorm stage 2: y = (x - mean) * rstd * gamma + beta  [SiLU];  concat folded into the read.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs a) {
+    constexpr int VE = Vec<T>::N;
+    typedef typename Vec<T>::type vec_t;
+    __shared__ float mean_s[64], rstd_s[64];
+    const int C = a.c0 + a.c1;
+    const int Cg = C / a.groups;
+    const int b = blockIdx.y;
+    if (threadIdx.x < a.groups) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+            const float* p = a.partial + (((size_t)b * a.nsplit + sp) * a.groups + threadIdx.x) * 2;
+            s1 += (double)p[0];
+            s2 += (double)p[1];
+        }
+        const double n = (double)a.HW * Cg;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[threadIdx.x] = (float)mean;
+        rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    const int vpr = C / VE;  // vectors per row
+    const long long total = (long long)a.HW * vpr;
+    T* y = reinterpret_cast<T*>(a.y) + (size_t)b * a.HW * C;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / vpr);
+        const int ch = (int)(i - (long long)r * vpr) * VE;
+        const T* src = ch < a.c0 ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                                 : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+        const vec_t x = *reinterpret_cast<const vec_t*>(src);
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const int c = ch + e;
+            const int gq = c / Cg;
+            float f = ((float)x[e] - mean_s[gq]) * rstd_s[gq] * a.gamma[c] + a.beta[c];
+            if (a.silu) f = silu_f(f);
+            o[e] = from_f32<T>(f);
+        }
+        *reinterpret_cast<vec_t*>(y + (size_t)r * C + ch) = o;
+    }
+}
+
+int groupnorm_nsplit(int B, int HW) {
+    int ns = 512 / (B > 0 ? B : 1);
+    if (ns < 1) ns = 1;
+    if (ns > HW / 8) ns = HW / 8;
+    if (ns < 1) ns = 1;
+    if (ns > 64) ns = 64;
+    return ns;
+}
+
+template <typename T>
+int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
+    constexpr int VE = Vec<T>::N;
+    const int C = a.c0 + a.c1;
+    MRISR_REQUIRE(C % a.groups == 0 && a.groups <= 64, "GroupNorm groups");
+    MRISR_REQUIRE(a.c0 % VE == 0 && a.c1 % VE == 0, "GroupNorm channel alignment");
+    MRISR_REQUIRE(a.partial != nullptr && a.nsplit >= 1, "GroupNorm workspace");
+    const int nvec = C / VE;
+    int vpt = 1;
+    while (nvec / vpt > 256 || (nvec % vpt) != 0) ++vpt;
+    MRISR_REQUIRE(vpt <= 4, "GroupNorm: too many channels for the stats kernel");
+    const int slots = nvec / vpt;
+    int RL = 256 / slots;
+    if (RL < 1) RL = 1;
+    const size_t smem = (size_t)2 * RL * C * sizeof(float);
+    dim3 grid(a.nsplit, a.B);
+    switch (vpt) {
+        case 1: hipLaunchKernelGGL((gn_stats_kernel<T, 1>), grid, dim3(256), smem, st, a, slots, RL); break;
+        case 2: hipLaunchKernelGGL((gn_stats_kernel<T, 2>), grid, dim3(256), smem, st, a, slots, RL); break;
+        case 3: hipLaunchKernelGGL((gn_stats_kernel<T, 3>), grid, dim3(256), smem, st, a, slots, RL); break;
+        default: hipLaunchKernelGGL((gn_stats_kernel<T, 4>), grid, dim3(256), smem, st, a, slots, RL); break;
+    }
+    MRISR_CHECK_HIP(hipGetLastError());
+    const long long total = (long long)a.HW * nvec;
+    int bx = (int)((total + 255) / 256);
+    const int cap = 2048 / (a.B > 0 ? a.B : 1) + 1;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(bx, a.B), dim3(256), 0, st, a);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per token row, the row lives in registers (<= MAXV 16-byte vectors per lane).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, int C, float eps) {
+    constexpr int VE = Vec<T>::N;
+    typedef typename Vec<T>::type vec_t;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nvec = C / VE;
+    float v[MAXV][VE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const vec_t t = *reinterpret_cast<const vec_t*>(x + (size_t)row * C + vi * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                v[i][e] = (float)t[e];
+                s += v[i][e];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            vec_t o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int c = vi * VE + e;
+                o[e] = from_f32<T>((v[i][e] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *reinterpret_cast<vec_t*>(y + (size_t)row * C + vi * VE) = o;
+        }
+    }
+}
+
+template <typename T>
+int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C, float eps,
+                     hipStream_t st) {
+    constexpr int VE = Vec<T>::N;
+    MRISR_REQUIRE(C % VE == 0, "LayerNorm channel alignment");
+    const int nvec = C / VE;
+    const int need = (nvec + 63) / 64;
+    const dim3 grid((M + 3) / 4);
+    const T* xi = reinterpret_cast<const T*>(x);
+    T* yo = reinterpret_cast<T*>(y);
+    if (need <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (need <= 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (need <= 3) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (need <= 5) hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (need <= 10) hipLaunchKernelGGL((layernorm_kernel<T, 10>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
+    else MRISR_REQUIRE(false, "LayerNorm: row too long");
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax for the materialised (f32 parity) attention: one wave per row.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int ld, T* __restrict__ p,
+                                                           int ldp, long long rows, int nk) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < nk; c += 64) mx = fmaxf(mx, sr[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < nk; c += 64) sum += expf(sr[c] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* pr = p + row * ldp;
+    for (int c = lane; c < ldp; c += 64) pr[c] = from_f32<T>(c < nk ? expf(sr[c] - mx) * inv : 0.f);
+}
+
+template <typename T>
+int launch_softmax_rows(const float* s, int ld, void* p, int ldp, long long rows, int nk, hipStream_t st) {
+    // NOTE: p may alias s only when sizeof(T) == 4 and ldp == ld (each lane rewrites what it alone read)
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipLaunchKernelGGL(softmax_rows_kernel<T>, grid, dim3(256), 0, st, s, ld, reinterpret_cast<T*>(p), ldp, rows, nk);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template int launch_groupnorm<float>(const GroupNormArgs&, hipStream_t);
+template int launch_groupnorm<bf16>(const GroupNormArgs&, hipStream_t);
+template int launch_layernorm<float>(const void*, void*, const float*, const float*, int, int, float, hipStream_t);
+template int launch_layernorm<bf16>(const void*, void*, const float*, const float*, int, int, float, hipStream_t);
+template int launch_softmax_rows<float>(const float*, int, void*, int, long long, int, hipStream_t);
+template int launch_softmax_rows<bf16>(const float*, int, void*, int, long long, int, hipStream_t);
+
+}  // namespace mrisr

@@ -1,0 +1,9 @@
+"""mrisr - MI355X-native denoiser hot path for MRI diffusion super-resolution (host-side Python over libmrisr.so).
+
+Importing the package does not need a GPU; constructing a model or calling an op does, and raises
+``MrisrError`` when the HIP library or device is missing.  There is no CPU fallback anywhere in this package."""
+from ._lib import LIB_PATH, MrisrError  # noqa: F401
+from .models import Adapter_XL, ControlNetModel, UNet2DConditionModel, UNetConfig  # noqa: F401
+from .pipeline import (Sampler, decode_to_vis, get_res_shifting_latents, log_validation,  # noqa: F401
+                       prepare_condition_image)
+from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401

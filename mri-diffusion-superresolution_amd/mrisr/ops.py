@@ -1,0 +1,94 @@
+"""Single-op entry points of the C ABI (``mrisr_op_*``): the same kernels the models launch, exposed so the parity
+tests can check each one against a plain PyTorch reference of the op."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _nhwc(x: torch.Tensor):
+    """torch NCHW tensor -> (contiguous NHWC buffer, descriptor with logical NCHW shape)."""
+    buf = x.permute(0, 2, 3, 1).contiguous()
+    return buf, L.as_tensor(buf, L.MRISR_NHWC, shape=x.shape)
+
+
+def _f32(x: Optional[torch.Tensor]):
+    return None if x is None else C.c_void_p(x.detach().to(torch.float32).contiguous().data_ptr())
+
+
+def conv3x3(x, weight, bias=None, x2=None, stride=1, upsample=False, act=L.ACT_NONE, splitk=0, tile=0):
+    """x [B,C,H,W] (bf16/f32, cuda), weight [Cout,Cin,3,3] f32.  Returns NCHW tensor of x.dtype."""
+    xb, tx = _nhwc(x)
+    t2 = None
+    if x2 is not None:
+        x2b, t2 = _nhwc(x2)
+    w = weight.detach().to(torch.float32).contiguous()
+    b = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+    B, _, H, W = x.shape
+    Hc, Wc = (H * 2, W * 2) if upsample else (H, W)
+    Ho, Wo = (Hc - 1) // stride + 1, (Wc - 1) // stride + 1
+    cout = w.shape[0]
+    yb = torch.empty((B, Ho, Wo, cout), dtype=x.dtype, device=x.device)
+    ty = L.as_tensor(yb, L.MRISR_NHWC, shape=(B, cout, Ho, Wo))
+    L.check(L.lib().mrisr_op_conv3x3(C.byref(tx), C.byref(t2) if t2 else None, C.c_void_p(w.data_ptr()),
+                                     C.c_void_p(b.data_ptr()) if b is not None else None, cout, stride,
+                                     1 if upsample else 0, act, splitk, tile, C.byref(ty), L.stream_ptr()))
+    return yb.permute(0, 3, 1, 2)
+
+
+def linear(x, weight, bias=None, act=L.ACT_NONE, splitk=0, tile=0):
+    """x [M,K], weight [N,K] f32 -> [M,N] (GEGLU: [M,N/2])."""
+    x = x.contiguous()
+    w = weight.detach().to(torch.float32).contiguous()
+    b = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+    n = w.shape[0]
+    y = torch.empty((x.shape[0], n // 2 if act == L.ACT_GEGLU else n), dtype=x.dtype, device=x.device)
+    tx, ty = L.as_tensor(x), L.as_tensor(y)
+    L.check(L.lib().mrisr_op_linear(C.byref(tx), C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(b.data_ptr()) if b is not None else None, n, act, splitk, tile,
+                                    C.byref(ty), L.stream_ptr()))
+    return y
+
+
+def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None):
+    xb, tx = _nhwc(x)
+    t2 = None
+    ctot = x.shape[1]
+    if x2 is not None:
+        x2b, t2 = _nhwc(x2)
+        ctot += x2.shape[1]
+    g = gamma.detach().to(torch.float32).contiguous()
+    b = beta.detach().to(torch.float32).contiguous()
+    B, _, H, W = x.shape
+    yb = torch.empty((B, H, W, ctot), dtype=x.dtype, device=x.device)
+    ty = L.as_tensor(yb, L.MRISR_NHWC, shape=(B, ctot, H, W))
+    L.check(L.lib().mrisr_op_groupnorm(C.byref(tx), C.byref(t2) if t2 else None, C.c_void_p(g.data_ptr()),
+                                       C.c_void_p(b.data_ptr()), groups, C.c_float(eps), 1 if silu else 0,
+                                       C.byref(ty), L.stream_ptr()))
+    return yb.permute(0, 3, 1, 2)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    x = x.contiguous()
+    g = gamma.detach().to(torch.float32).contiguous()
+    b = beta.detach().to(torch.float32).contiguous()
+    y = torch.empty_like(x)
+    tx, ty = L.as_tensor(x), L.as_tensor(y)
+    L.check(L.lib().mrisr_op_layernorm(C.byref(tx), C.c_void_p(g.data_ptr()), C.c_void_p(b.data_ptr()), C.c_float(eps),
+                                       C.byref(ty), L.stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return y
+
+
+def attention(q, k, v, heads, flash=True):
+    """q [B,N,C], k/v [B,Nk,C] -> [B,N,C]  (softmax(q k^T / sqrt(d)) v per head)."""
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    out = torch.empty_like(q)
+    tq, tk, tv, to = (L.as_tensor(t) for t in (q, k, v, out))
+    L.check(L.lib().mrisr_op_attention(C.byref(tq), C.byref(tk), C.byref(tv), heads, 1 if flash else 0, C.byref(to),
+                                       L.stream_ptr()))
+    return out

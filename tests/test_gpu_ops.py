@@ -1,0 +1,137 @@
+"""GPU: each HIP kernel class against a plain PyTorch fp32 reference of the same op, through the C ABI
+(mrisr_op_*).  Tolerances: f32 path 1e-3 relative (north_star); bf16 path compared against the fp32 reference of the
+bf16-rounded inputs with a relative-L2 bound (bf16 has 8 mantissa bits)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f32": 1e-3, "bf16": 1.2e-2}
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def _rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DT[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K,tile,splitk", [
+    (256, 128, 128, 1, 1), (300, 320, 320, 0, 1), (1000, 64, 192, 2, 1), (77, 640, 768, 3, 1),
+    (512, 1280, 2560, 4, 1), (512, 256, 4096, 1, 4), (130, 68, 256, 4, 3), (2048, 320, 320, 2, 1),
+])
+def test_linear(dt, M, N, K, tile, splitk):
+    from mrisr import ops
+    x, w, b = _rnd((M, K), dt, 1), _rnd((N, K), "f32", 2, K ** -0.5), _rnd((N,), "f32", 3)
+    wq = w.to(DT[dt]).float()
+    ref = F.linear(x.float(), wq, b)
+    y = ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=tile, splitk=splitk)
+    assert rel(y, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_linear_geglu_and_activations(dt):
+    from mrisr import _lib as L
+    from mrisr import ops
+    M, C = 384, 128
+    x, w, b = _rnd((M, C), dt, 4), _rnd((8 * C, C), "f32", 5, C ** -0.5), _rnd((8 * C,), "f32", 6)
+    h = F.linear(x.float(), w.to(DT[dt]).float(), b)
+    u, g = h.chunk(2, dim=-1)
+    ref = u * F.gelu(g)
+    y = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=L.ACT_GEGLU)
+    assert y.shape == (M, 4 * C) and rel(y, ref) < TOL[dt]
+    for act, fn in ((L.ACT_RELU, F.relu), (L.ACT_SILU, F.silu)):
+        y = ops.linear(x.cuda(), w[:256].cuda(), b[:256].cuda(), act=act)
+        assert rel(y, fn(h[:, :256])) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,stride,ups,tile,splitk", [
+    (2, 64, 64, 16, 1, False, 0, 1), (1, 128, 320, 12, 1, False, 1, 1), (2, 64, 128, 16, 2, False, 3, 1),
+    (2, 128, 64, 8, 1, True, 2, 1), (3, 256, 256, 4, 1, False, 1, 5), (1, 64, 64, 5, 1, False, 4, 2),
+    (1, 320, 320, 32, 1, False, 2, 1),
+])
+def test_conv3x3(dt, B, Cin, Cout, H, stride, ups, tile, splitk):
+    from mrisr import ops
+    x = _rnd((B, Cin, H, H), dt, 7)
+    w, b = _rnd((Cout, Cin, 3, 3), "f32", 8, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 9)
+    xi = x.float()
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xi, w.to(DT[dt]).float(), b, stride=stride, padding=1)
+    y = ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), stride=stride, upsample=ups, tile=tile, splitk=splitk)
+    assert y.shape == ref.shape and rel(y, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv3x3_skip_concat(dt):
+    from mrisr import ops
+    x1, x2 = _rnd((2, 128, 8, 8), dt, 10), _rnd((2, 64, 8, 8), dt, 11)
+    w, b = _rnd((128, 192, 3, 3), "f32", 12, (9 * 192) ** -0.5), _rnd((128,), "f32", 13)
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), w.to(DT[dt]).float(), b, padding=1)
+    y = ops.conv3x3(x1.cuda(), w.cuda(), b.cuda(), x2=x2.cuda())
+    assert rel(y, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,C2,H,silu", [(2, 320, 0, 16, True), (3, 64, 0, 8, False), (2, 1280, 640, 8, True),
+                                           (1, 2560, 0, 4, True), (2, 640, 320, 32, True), (32, 64, 64, 4, False)])
+def test_groupnorm(dt, B, C, C2, H, silu):
+    from mrisr import ops
+    x = _rnd((B, C, H, H), dt, 14) * 1.7 + 0.3
+    x2 = _rnd((B, C2, H, H), dt, 15) if C2 else None
+    g, b = 1 + 0.2 * _rnd((C + C2,), "f32", 16), 0.2 * _rnd((C + C2,), "f32", 17)
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], 1)
+    ref = F.group_norm(xin, 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), 32, 1e-5, silu, x2=x2.cuda() if x2 is not None else None)
+    assert rel(y, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,C", [(100, 320), (64, 640), (33, 1280), (7, 64)])
+def test_layernorm(dt, M, C):
+    from mrisr import ops
+    x = _rnd((M, C), dt, 18) * 2 + 0.5
+    g, b = 1 + 0.2 * _rnd((C,), "f32", 19), 0.2 * _rnd((C,), "f32", 20)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5)
+    assert rel(ops.layernorm(x.cuda(), g.cuda(), b.cuda()), ref) < TOL[dt]
+
+
+def _sdpa(q, k, v, H):
+    B, N, C = q.shape
+    d = C // H
+    qh, kh, vh = (t.float().view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("dt,flash", [("f32", False), ("bf16", False), ("bf16", True)])
+@pytest.mark.parametrize("B,N,Nk,C,H", [(2, 256, 256, 320, 8), (1, 1024, 1024, 320, 8), (2, 64, 64, 1280, 8),
+                                        (2, 16, 16, 1280, 8), (2, 256, 77, 640, 8), (1, 200, 77, 64, 8),
+                                        (1, 64, 64, 256, 8)])
+def test_attention(dt, flash, B, N, Nk, C, H):
+    from mrisr import ops
+    q, k, v = _rnd((B, N, C), dt, 21), _rnd((B, Nk, C), dt, 22), _rnd((B, Nk, C), dt, 23)
+    ref = _sdpa(q, k, v, H)
+    y = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, flash=flash)
+    assert rel(y, ref) < (2e-2 if dt == "bf16" else 1e-3)
+
+
+def test_attention_flash_online_softmax_rescale_branch():
+    """Force the running max to jump late in the key sequence (guide rule 26): one key aligned with every query
+    sits in the LAST tile, so all earlier tiles' accumulators must be rescaled by exp(m_old - m_new)."""
+    from mrisr import ops
+    B, N, C, H = 1, 256, 320, 8
+    q, k, v = _rnd((B, N, C), "bf16", 24), _rnd((B, N, C), "bf16", 25), _rnd((B, N, C), "bf16", 26)
+    k[:, 250] = q.float().mean(1) .to(torch.bfloat16) * 6.0
+    ref = _sdpa(q, k, v, H)
+    y = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, flash=True)
+    assert rel(y, ref) < 2e-2

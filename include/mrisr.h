@@ -143,6 +143,10 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
                       const mrisr_tensor* step_noise, const mrisr_tensor* ehs, const mrisr_tensor* cond,
                       const mrisr_tensor* intrablock, int n_intrablock, int use_graph, void* stream);
 
+/* Restrict the next runs to steps [first_step, last_step) of the schedule (default: all).  Step i always uses the
+ * schedule's own (t_i, t_{i+1}) pair, so a truncated run reproduces the prefix of the full trajectory. */
+int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step);
+
 /* ---- single-op entry points (used by the parity tests; same kernels the models launch) ------------ */
 int mrisr_op_conv3x3(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, const float* w_oihw_dev,
                      const float* bias_dev, int cout, int stride, int upsample, int act, int splitk, int tile,

@@ -147,7 +147,7 @@ __global__ void load_t_kernel(long long* cur_t, const long long* table, const in
 struct mrisr_sampler {
     mrisr_model* unet = nullptr;
     mrisr_model* cnet = nullptr;
-    int kind = 0, n_steps = 0;
+    int kind = 0, n_steps = 0, first = 0, last = 0;
     DevBuf d_ts, d_coef, d_step, d_curt, d_eps;
     std::vector<std::unique_ptr<DevBuf>> res_bufs;   // ControlNet -> UNet residuals (NHWC, compute dtype)
     std::vector<std::unique_ptr<DevBuf>> intra_bufs;  // adapter features converted once
@@ -175,6 +175,8 @@ int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_ki
     s->cnet = controlnet;
     s->kind = step_kind;
     s->n_steps = n_steps;
+    s->first = 0;
+    s->last = n_steps;
     std::vector<long long> ts(timesteps, timesteps + n_steps);
     std::vector<float> coef((size_t)n_steps * 4, 0.f);
     for (int i = 0; i < n_steps; ++i) {
@@ -208,6 +210,12 @@ int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_ki
     API_END
 }
 void mrisr_sampler_destroy(mrisr_sampler* s) { delete s; }
+int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step) {
+    MRISR_REQUIRE(s && first_step >= 0 && first_step <= last_step && last_step <= s->n_steps, "step range");
+    s->first = first_step;
+    s->last = last_step;
+    return 0;
+}
 
 int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tensor* lr_latents,
                       const mrisr_tensor* step_noise, const mrisr_tensor* ehs, const mrisr_tensor* cond,
@@ -278,6 +286,7 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
     }
     TRY(s->d_eps.reserve((size_t)n * sizeof(float), false));
     MRISR_CHECK_HIP(hipMemsetAsync(s->d_step.p, 0, 16, st));
+    MRISR_CHECK_HIP(hipMemcpyAsync(s->d_step.p, &s->first, sizeof(int), hipMemcpyHostToDevice, st));
 
     mrisr_tensor tt{};
     tt.data = s->d_curt.p; tt.dtype = MRISR_I64; tt.ndim = 0;
@@ -301,7 +310,7 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
     };
 
     if (!use_graph) {
-        for (int i = 0; i < s->n_steps; ++i) TRY(body());
+        for (int i = s->first; i < s->last; ++i) TRY(body());
     } else {
         char key[160];
         snprintf(key, sizeof(key), "%d,%d,%d,%d,%p,%p,%p,%d", B, h, w, L, latents->data, lr_latents ? lr_latents->data : nullptr,
@@ -319,7 +328,7 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
             (void)hipGraphDestroy(graph);
             s->graph_key = key;
         }
-        for (int i = 0; i < s->n_steps; ++i) MRISR_CHECK_HIP(hipGraphLaunch(s->exec, st));
+        for (int i = s->first; i < s->last; ++i) MRISR_CHECK_HIP(hipGraphLaunch(s->exec, st));
     }
     if (st != user) {
         MRISR_CHECK_HIP(hipEventRecord(s->ev_out, st));

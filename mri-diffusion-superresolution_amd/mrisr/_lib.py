@@ -51,7 +51,7 @@ EXPORTS = [
     "mrisr_model_workspace_bytes", "mrisr_unet_forward", "mrisr_model_set_context", "mrisr_model_num_skips",
     "mrisr_model_skip_shape", "mrisr_controlnet_forward", "mrisr_controlnet_set_cond", "mrisr_adapter_create",
     "mrisr_adapter_destroy", "mrisr_adapter_set_param", "mrisr_adapter_finalize", "mrisr_adapter_forward",
-    "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run",
+    "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range",
     "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
 ]
 

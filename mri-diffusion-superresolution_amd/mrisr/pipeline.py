@@ -78,6 +78,10 @@ class Sampler:
         except Exception:
             pass
 
+    def set_range(self, first_step: int, last_step: int):
+        """Run only steps [first_step, last_step) of the schedule on the next ``run`` (resume / inspection)."""
+        L.check(L.lib().mrisr_sampler_set_range(self._h, int(first_step), int(last_step)))
+
     def run(self, latents: torch.Tensor, encoder_hidden_states: torch.Tensor, lr_latents: Optional[torch.Tensor] = None,
             step_noise: Optional[torch.Tensor] = None, controlnet_cond: Optional[torch.Tensor] = None,
             adapter_features: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True) -> torch.Tensor:

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): MRI slices/sec for a 50-step DDIM(eta=0) sample at 256^2 px
+(-> 4x32x32 latents), B=32 slices per GPU, SD-1.5-size UNet + rank-4 LoRA fused into the projection GEMMs.
+
+One "step" = one batch of 32 synthetic slices through all 50 denoising steps (50 hipGraph replays of
+UNet forward + fused DDIM update), inputs resident in HBM.  One process per GPU; inference shards over
+independent slices, so there is NO data-path collective (weak scaling) - torch.distributed is used only for
+the barrier and the max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how every field is derived).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mri-diffusion-superresolution_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+SEED = 20260501
+B_PER_GPU = 32
+LATENT = 32
+N_DDIM = 50
+UNET_GFLOP_PER_SAMPLE = 180.27  # algorithmic 2*MAC FLOPs of one UNet forward @32^2 latents
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(B, device, rank):
+    """Procedural brain-like phantoms -> LR anchor latents (stub VAE: avgpool8 * 0.18215), context, x_T."""
+    g = torch.Generator(device=device).manual_seed(SEED + 1000 * rank)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256, device=device), torch.linspace(-1, 1, 256, device=device), indexing="ij")
+    imgs = []
+    for i in range(B):
+        r = torch.rand(6, device=device, generator=g)
+        head = ((xx / (0.7 + 0.1 * r[0])) ** 2 + (yy / (0.85 + 0.1 * r[1])) ** 2 < 1).float()
+        inner = ((xx - 0.2 * (r[2] - 0.5)) ** 2 / 0.25 + (yy - 0.2 * (r[3] - 0.5)) ** 2 / 0.36 < 1).float()
+        tex = torch.nn.functional.interpolate(torch.randn(1, 1, 16, 16, device=device, generator=g), size=(256, 256),
+                                              mode="bicubic", align_corners=False)[0, 0]
+        imgs.append((0.6 * head + 0.3 * inner + 0.1 * tex * head).clamp(0, 1) * 2 - 1)
+    hr = torch.stack(imgs)[:, None]
+    lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 4), scale_factor=4.0, mode="bicubic").clamp(-1, 1)
+    lr_lat = (torch.nn.functional.avg_pool2d(lr, 8).repeat(1, 4, 1, 1) * 0.18215).contiguous()
+    ctx = torch.randn((B, 77, 768), device=device, generator=g)
+    noise = torch.randn(lr_lat.shape, device=device, generator=g)
+    return lr_lat, ctx, noise
+
+
+def prof_report(lib):
+    buf = C.create_string_buffer(1 << 16)
+    n = lib.mrisr_prof_report(buf, len(buf))
+    return json.loads(buf.value.decode()) if n > 0 else {}
+
+
+def cpu_baseline(state_dict_cpu, cfg_oracle, threads):
+    """The oracle (CPU restatement of the reference's diffusers path) on this box's host cores: B=2, 1 warm-up +
+    3 timed sample-steps (bounded sample), extrapolated to slices/s by / 50 steps."""
+    from oracle import unet as ou
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(SEED + 7)
+    x = torch.randn((2, 4, LATENT, LATENT), generator=g)
+    ctx = torch.randn((2, 77, 768), generator=g)
+    with torch.no_grad():
+        ou.unet_forward(state_dict_cpu, cfg_oracle, x, torch.tensor(981), ctx)
+        t0 = time.perf_counter()
+        n = 3
+        for i in range(n):
+            ou.unet_forward(state_dict_cpu, cfg_oracle, x, torch.tensor(961 - 20 * i), ctx)
+        dt = time.perf_counter() - t0
+    sample_steps_per_s = 2 * n / dt
+    return {"value": sample_steps_per_s / N_DDIM, "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle UNet fwd fp32, B=2, 1 warm-up + {n} timed sample-steps ({dt:.1f} s), /{N_DDIM} steps (extrapolated)",
+            "sample_steps_per_s": sample_steps_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="slices per GPU (BASELINE config: 32)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lora-merged", action="store_true", help="merge LoRA into W instead of the fused rank tail")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL; barrier + max-reduce of the time only
+
+    import mrisr
+    from mrisr import _lib as L
+    from mrisr import params as P
+
+    cfg = mrisr.UNetConfig()
+    sd = P.random_state_dict(P.unet_param_shapes(cfg), SEED, dev)
+    sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), SEED + 3, dev))
+    unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype, lora_rank=4, lora_alpha=4,
+                                      lora_fused=not args.lora_merged, flash_attention=True)
+    unet.load_state_dict(sd)
+    sched = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
+    sched.set_timesteps(N_DDIM)
+    sampler = mrisr.Sampler(unet, sched, kind="ddim")
+    B = args.batch
+    lr_lat, ctx, noise = synthetic_batch(B, dev, rank)
+    a_T = float(sched.alphas_cumprod[int(sched.timesteps[0])])
+    x_T = (lr_lat + (1 - a_T) ** 0.5 * noise).contiguous()  # reference res_srdiff.py:58
+    lat = torch.empty_like(x_T)
+
+    def one_batch():
+        lat.copy_(x_T)
+        sampler.run(lat, ctx, use_graph=not args.no_graph)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_batch()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        one_batch()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(lat).all())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline leg: the same workload, eager launches, a HIP event pair around EVERY kernel launch on the launch
+    # stream (libmrisr's own profiler), aggregated per kernel class; two denoising steps.
+    lib = L.lib()
+    lib.mrisr_prof_reset()
+    lib.mrisr_prof_enable(1)
+    sampler2 = mrisr.Sampler(unet, sched, kind="ddim")
+    sampler2.set_range(0, 2)
+    lat.copy_(x_T)
+    sampler2.run(lat, ctx, use_graph=False)
+    torch.cuda.synchronize()
+    lib.mrisr_prof_enable(0)
+    classes = prof_report(lib)
+    lib.mrisr_prof_reset()
+    total_ms = sum(v["ms"] for v in classes.values()) or 1.0
+    gemm = {k: v for k, v in classes.items() if k.startswith("gemm_")}
+    dom_name = max(gemm, key=lambda k: gemm[k]["ms"]) if gemm else None
+    roof = None
+    if dom_name:
+        d = gemm[dom_name]
+        per_launch_ms = d["ms"] / d["launches"]
+        achieved = d["flops"] / d["launches"] / (per_launch_ms * 1e-3) / 1e12
+        all_fl = sum(v["flops"] for v in gemm.values())
+        all_ms = sum(v["ms"] for v in gemm.values())
+        roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+                "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": None,
+                "launches": d["launches"], "avg_launch_us": per_launch_ms * 1e3,
+                "alg_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                "share_of_step_time": d["ms"] / total_ms,
+                "all_gemm": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "share_of_step_time": all_ms / total_ms,
+                             "alg_gflop_per_unet_step": all_fl / 2 / 1e9},
+                "classes_ms_per_step": {k: round(v["ms"] / 2, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["ms"])}}
+
+    total_slices = world * B * args.steps
+    value = total_slices / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    step_ms = ms_per_step / N_DDIM
+    out = {
+        "metric": "MRI slices/sec (50-step DDIM, 256^2, bs=32)", "value": value, "unit": "slices/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: 256x256 1-ch synthetic MRI slices -> 4x32x32 latents, SD-1.5-size UNet "
+                               "(859.5M params, random init) + rank-4 LoRA, 50-step DDIM, bs=32 per GPU",
+                   "slices_per_gpu_per_step": B, "ddim_steps": N_DDIM, "parallelism": f"slice-sharded x{world} (no collective)",
+                   "lora": "merged" if args.lora_merged else "fused rank tail", "hipgraph": not args.no_graph},
+        "denoise_step_ms": step_ms,
+        "unet_tflops_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms / 1e3,
+        "frac_of_bf16_peak_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms / 1e3 / PEAK_BF16_TFLOPS,
+        "finite": finite,
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import unet as ou
+        threads = os.cpu_count() or 1
+        sd_cpu = {k: v.detach().float().cpu() for k, v in sd.items()}
+        out["cpu_baseline"] = cpu_baseline(sd_cpu, ou.SD15, threads)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,6 +147,12 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
  * schedule's own (t_i, t_{i+1}) pair, so a truncated run reproduces the prefix of the full trajectory. */
 int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step);
 
+/* ---- per-launch HIP-event profiler (bench.py roofline leg; off by default) ------------------------- */
+int mrisr_prof_enable(int on);
+int mrisr_prof_reset(void);
+/* JSON {"<kernel class>": {"launches", "ms", "flops", "bytes"}}; returns the length written or -1 if buf is too small */
+int mrisr_prof_report(char* buf, int cap);
+
 /* ---- single-op entry points (used by the parity tests; same kernels the models launch) ------------ */
 int mrisr_op_conv3x3(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, const float* w_oihw_dev,
                      const float* bias_dev, int cout, int stride, int upsample, int act, int splitk, int tile,

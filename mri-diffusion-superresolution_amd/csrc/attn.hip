@@ -8,6 +8,7 @@
 // are per-lane scalars.  Operands arrive head-major ([b*h][token][dpad], V already transposed
 // [b*h][dpad][token]) straight from the QKV GEMM epilogue; padding rows/columns are zero.
 #include "common.h"
+#include "prof.h"
 
 namespace mrisr {
 
@@ -185,6 +186,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 template <int DPAD>
 static int launch_dpad(const AttnArgs& a, hipStream_t st) {
     const int BH = a.B * a.H;
+    ProfScope ps("flash_attention", 4.0 * BH * (double)a.nq * a.nk * a.hd,
+                 2.0 * BH * (2.0 * a.nq * a.hd + 2.0 * a.nk * a.hd), st);
     if (a.nq >= 128) {
         hipLaunchKernelGGL((attn_fwd_kernel<DPAD, 2>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
     } else {

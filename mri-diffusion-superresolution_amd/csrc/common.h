@@ -94,6 +94,8 @@ struct GemmArgs {
     void* sec_ptr[3] = {nullptr, nullptr, nullptr};
     int sec_tr[3] = {0, 0, 0};      // 1: store transposed [b][h][dd][tok] (V^T), else [b][h][tok][dd]
     int secC = 0, hd = 0, dpad = 0, ntok = 0, npad = 0, nheads = 0;
+    // profiler only: algorithmic work of this launch (0 -> derived from M, N, K)
+    double alg_flops = 0.0, alg_bytes = 0.0;
 };
 
 int gemm_workspace_splitk(const GemmArgs& g);  // recommended split (1 = none)

@@ -13,6 +13,7 @@
 //    GEGLU gate, residual) is per-lane and the store is one 8/16-byte word per (m, 4n);
 //  * bf16 path: v_mfma_f32_16x16x32_bf16;  f32 parity path: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
 #include "common.h"
+#include "prof.h"
 
 namespace mrisr {
 
@@ -410,6 +411,16 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     if (prepare_cfg<T, BM, BN, WGM, WGN>()) return 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     dim3 grid(ntn * ntm, g.splitk, g.batch);
+    static const std::string pname = std::string("gemm_") + (sizeof(T) == 2 ? "bf16_" : "f32_") + std::to_string(BM) + "x" + std::to_string(BN);
+    double fl = g.alg_flops, by = g.alg_bytes;
+    if (prof_enabled()) {
+        if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K * g.batch;
+        if (by == 0.0) {
+            const double a_el = g.conv ? (double)g.B * g.Hin * g.Win * (g.c0 + g.c1) : (double)g.M * g.K;
+            by = sizeof(T) * g.batch * (a_el + (double)g.N * g.K + (double)g.M * g.N);
+        }
+    }
+    ProfScope ps(pname.c_str(), fl, by, st);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g, (const char*)zero_page());
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -469,6 +480,7 @@ int launch_splitk_reduce(const GemmArgs& g, hipStream_t st) {
     const long long total = (long long)g.M * (g.N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    ProfScope ps("splitk_reduce", 0.0, (double)g.batch * g.M * g.N * (4.0 * g.splitk + sizeof(T)), st);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks, 1, g.batch), dim3(256), 0, st, g);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;

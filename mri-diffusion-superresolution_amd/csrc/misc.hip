@@ -1,6 +1,7 @@
 // Small / bandwidth-bound kernels: time-embedding GEMV, direct convolutions for tiny channel counts,
 // NCHW<->NHWC boundary conversion, weight packers, and the fused sampler steps.
 #include "common.h"
+#include "prof.h"
 
 namespace mrisr {
 
@@ -64,6 +65,7 @@ int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, 
                      int K, int silu_in, hipStream_t st) {
     MRISR_REQUIRE(K % (16 / (int)sizeof(T)) == 0, "gemv K alignment");
     const dim3 grid((N + 3) / 4);
+    ProfScope ps("time_embed_gemv", 2.0 * rows * (double)N * K, (double)N * K * sizeof(T), st);
     if (rows <= 1)
         hipLaunchKernelGGL((gemv_rows_kernel<T, 1>), grid, dim3(256), 0, st, x, ldx, reinterpret_cast<const T*>(w), bias,
                            y, ldy, rows, N, K, silu_in);
@@ -133,6 +135,8 @@ int launch_direct_conv(const DirectConvArgs& a, hipStream_t st) {
     const long long total = (long long)a.B * a.Hout * a.Wout * a.Cout;
     long long blocks = (total + 255) / 256;
     if (blocks > 65535 * 4) blocks = 65535 * 4;
+    ProfScope ps("direct_conv", 2.0 * total * a.ks * a.ks * a.Cin,
+                 sizeof(T) * ((double)a.B * a.Hin * a.Win * a.Cin + (double)total), st);
     hipLaunchKernelGGL(direct_conv_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -188,6 +192,7 @@ static inline unsigned nblocks(long long total) {
 }
 template <typename T>
 int launch_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, hipStream_t st) {
+    ProfScope ps("layout_convert", 0.0, (double)B * C * H * W * (sizeof(T) + 4.0), st);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(nblocks((long long)B * C * H * W)), dim3(256), 0, st, src,
                        src_dtype, reinterpret_cast<T*>(dst), B, C, H, W);
     MRISR_CHECK_HIP(hipGetLastError());
@@ -196,6 +201,7 @@ int launch_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int B, int C,
 template <typename T>
 int launch_nhwc_to_nchw(const void* src, void* dst, int dst_dtype, int B, int C, int H, int W, float scale,
                         hipStream_t st) {
+    ProfScope ps("layout_convert", 0.0, (double)B * C * H * W * (sizeof(T) + 4.0), st);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(nblocks((long long)B * C * H * W)), dim3(256), 0, st,
                        reinterpret_cast<const T*>(src), dst, dst_dtype, B, C, H, W, scale);
     MRISR_CHECK_HIP(hipGetLastError());
@@ -209,6 +215,7 @@ __global__ void add_inplace_kernel(T* x, const T* y, long long n) {
 }
 template <typename T>
 int launch_add_inplace(void* x, const void* y, long long n, hipStream_t st) {
+    ProfScope ps("residual_add", 0.0, 3.0 * n * sizeof(T), st);
     hipLaunchKernelGGL(add_inplace_kernel<T>, dim3(nblocks(n)), dim3(256), 0, st, reinterpret_cast<T*>(x),
                        reinterpret_cast<const T*>(y), n);
     MRISR_CHECK_HIP(hipGetLastError());
@@ -320,6 +327,7 @@ __global__ void ddim_step_kernel(float* x, const float* eps, const float* coef, 
 }
 int launch_ddim_step(float* x, const float* eps, const float* coef_table, const int* step_idx, long long n,
                      hipStream_t st) {
+    ProfScope ps("sampler_step", 0.0, 12.0 * n, st);
     hipLaunchKernelGGL(ddim_step_kernel, dim3(nblocks(n)), dim3(256), 0, st, x, eps, coef_table, step_idx, n);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -340,6 +348,7 @@ __global__ void resshift_step_kernel(float* x, const float* eps, const float* lr
 }
 int launch_resshift_step(float* x, const float* eps, const float* lr, const float* noise, const float* coef_table,
                          const int* step_idx, long long n, hipStream_t st) {
+    ProfScope ps("sampler_step", 0.0, 20.0 * n, st);
     hipLaunchKernelGGL(resshift_step_kernel, dim3(nblocks(n)), dim3(256), 0, st, x, eps, lr, noise, coef_table,
                        step_idx, n);
     MRISR_CHECK_HIP(hipGetLastError());

@@ -118,6 +118,7 @@ struct Packer {
         l.n = ntot;
         l.k = k;
         l.rpad = (any_lora && fused_lora) ? round_up(rsum, BK) : 0;
+        l.r = l.rpad ? rsum : 0;
         const int ktot = k + l.rpad;
         l.w = m.new_packed((size_t)ntot * ktot * sizeof(T), l.rpad > 0);
         if (!l.w) { err = 4; return l; }
@@ -428,10 +429,12 @@ struct Runner {
             GemmArgs d;
             d.a0 = x; d.c0 = lw.k; d.lda0 = lda; d.w = lw.loraA; d.M = M; d.N = lw.rpad; d.K = lw.k;
             d.out = z; d.ldo = lw.rpad;
+            d.alg_flops = 2.0 * M * (double)lw.r * lw.k;
             TRY(run_gemm(d));
             g.a1 = z; g.c1 = lw.rpad; g.lda1 = lw.rpad;
         }
         g.w = lw.w; g.M = M; g.N = lw.n; g.K = lw.k + lw.rpad;
+        g.alg_flops = 2.0 * M * (double)lw.n * (lw.k + lw.r);
         g.bias = lw.b; g.act = act; g.resid = resid; g.ldr = ldr;
         if (g.out_mode != OUT_HEADS) { g.out = out; g.ldo = ldo; }
         TRY(run_gemm(g));

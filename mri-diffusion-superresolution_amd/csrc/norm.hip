@@ -2,6 +2,7 @@
 // LayerNorm over token rows, and the row softmax of the f32 parity attention.  All HBM-bound: 16-byte
 // vector accesses, f32 statistics, deterministic two-stage reductions (no float atomics).
 #include "common.h"
+#include "prof.h"
 
 namespace mrisr {
 
@@ -149,17 +150,22 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     if (RL < 1) RL = 1;
     const size_t smem = (size_t)2 * RL * C * sizeof(float);
     dim3 grid(a.nsplit, a.B);
+    const double act_bytes = (double)a.B * a.HW * C * sizeof(T);
+    {
+    ProfScope ps("groupnorm_stats", 0.0, act_bytes, st);
     switch (vpt) {
         case 1: hipLaunchKernelGGL((gn_stats_kernel<T, 1>), grid, dim3(256), smem, st, a, slots, RL); break;
         case 2: hipLaunchKernelGGL((gn_stats_kernel<T, 2>), grid, dim3(256), smem, st, a, slots, RL); break;
         case 3: hipLaunchKernelGGL((gn_stats_kernel<T, 3>), grid, dim3(256), smem, st, a, slots, RL); break;
         default: hipLaunchKernelGGL((gn_stats_kernel<T, 4>), grid, dim3(256), smem, st, a, slots, RL); break;
     }
+    }
     MRISR_CHECK_HIP(hipGetLastError());
     const long long total = (long long)a.HW * nvec;
     int bx = (int)((total + 255) / 256);
     const int cap = 2048 / (a.B > 0 ? a.B : 1) + 1;
     if (bx > cap) bx = cap;
+    ProfScope ps2("groupnorm_apply", 0.0, 2.0 * act_bytes, st);
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(bx, a.B), dim3(256), 0, st, a);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -242,6 +248,7 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
     const dim3 grid((M + 3) / 4);
     const T* xi = reinterpret_cast<const T*>(x);
     T* yo = reinterpret_cast<T*>(y);
+    ProfScope ps("layernorm", 0.0, 2.0 * M * (double)C * sizeof(T), st);
     if (need <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
     else if (need <= 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
     else if (need <= 3) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
@@ -277,6 +284,7 @@ template <typename T>
 int launch_softmax_rows(const float* s, int ld, void* p, int ldp, long long rows, int nk, hipStream_t st) {
     // NOTE: p may alias s only when sizeof(T) == 4 and ldp == ld (each lane rewrites what it alone read)
     const dim3 grid((unsigned)((rows + 3) / 4));
+    ProfScope ps("softmax_rows", 0.0, (double)rows * ld * (4.0 + sizeof(T)), st);
     hipLaunchKernelGGL(softmax_rows_kernel<T>, grid, dim3(256), 0, st, s, ld, reinterpret_cast<T*>(p), ldp, rows, nk);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;

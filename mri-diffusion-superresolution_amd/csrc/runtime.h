@@ -74,7 +74,7 @@ struct ConvW {  // packed [cout][ks*ks*cin] in compute dtype, bias f32
 struct LinW {  // packed [n][ktot] in compute dtype (ktot = k + rpad), bias f32 (GEGLU: interleaved)
     void* w = nullptr;
     const float* b = nullptr;
-    int n = 0, k = 0, rpad = 0;
+    int n = 0, k = 0, rpad = 0, r = 0;  // r: sum of the LoRA ranks riding in the K tail (rpad = r rounded to a K tile)
     void* loraA = nullptr;  // [rpad][k] compute dtype (rows >= used rank are zero) or null
 };
 

@@ -52,6 +52,7 @@ EXPORTS = [
     "mrisr_model_skip_shape", "mrisr_controlnet_forward", "mrisr_controlnet_set_cond", "mrisr_adapter_create",
     "mrisr_adapter_destroy", "mrisr_adapter_set_param", "mrisr_adapter_finalize", "mrisr_adapter_forward",
     "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range",
+    "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
     "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
 ]
 

@@ -99,7 +99,8 @@ class Sampler:
         keep = (ehs, lr, nz, cond, feats)  # noqa: F841  keep alive until the stream has consumed them
         t_lat, t_e = L.as_tensor(latents), L.as_tensor(ehs)
         t_lr = L.as_tensor(lr) if lr is not None else None
-        t_nz = L.as_tensor(nz) if nz is not None else None
+        # step noise is [n_stochastic_steps, B, C, h, w]: described to the C ABI as a stack of [B,C,h,w] slabs
+        t_nz = L.as_tensor(nz, shape=(nz.shape[0] * nz.shape[1],) + tuple(nz.shape[2:])) if nz is not None else None
         t_c = L.as_tensor(cond) if cond is not None else None
         f_arr = L.tensor_array([L.as_tensor(f) for f in feats])
         L.check(L.lib().mrisr_sampler_run(self._h, C.byref(t_lat), C.byref(t_lr) if t_lr else None,

@@ -67,3 +67,26 @@ def test_config_mirror():
     assert c.down_block_types[-1] == "DownBlock2D" and c.cross_attention_dim == 64
     d = mrisr.UNetConfig()
     assert d.block_out_channels == (320, 640, 1280, 1280) and d.cross_attention_dim == 768
+
+
+def test_state_dict_templates_match_oracle_and_known_counts():
+    """Product-side key/shape templates == the oracle's dictionaries; SD-1.5 totals are the known answers."""
+    import math
+
+    import mrisr
+    from mrisr import params as P
+    from oracle import unet as ou
+    tiny = mrisr.UNetConfig.from_oracle_like(ou.TINY)
+    up = ou.init_unet_params(ou.TINY, seed=1)
+    tmpl = {k: s for k, s, _ in P.unet_param_shapes(tiny)}
+    assert set(tmpl) == set(up) and all(tuple(up[k].shape) == tmpl[k] for k in up)
+    cp = ou.init_controlnet_params(ou.TINY, seed=1)
+    tmpl = {k: s for k, s, _ in P.controlnet_param_shapes(tiny)}
+    assert set(tmpl) == set(cp) and all(tuple(cp[k].shape) == tmpl[k] for k in cp)
+    lo = ou.init_lora_params(up, rank=4)
+    tmpl = {k: s for k, s, _ in P.lora_param_shapes(tiny, 4)}
+    assert set(tmpl) == set(lo) and all(tuple(lo[k].shape) == tmpl[k] for k in lo)
+    sd15 = mrisr.UNetConfig()
+    assert sum(math.prod(s) for _, s, _ in P.unet_param_shapes(sd15)) == 859_520_964
+    assert sum(math.prod(s) for _, s, _ in P.controlnet_param_shapes(sd15)) == 361_279_120
+    assert sum(math.prod(s) for _, s, _ in P.lora_param_shapes(sd15, 4)) == 797_184

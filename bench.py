@@ -36,6 +36,22 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (guides/MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU share of this process (cgroup/affinity aware), capped at 16 = one GPU's share of the box."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def synthetic_batch(B, device, rank):
     """Procedural brain-like phantoms -> LR anchor latents (stub VAE: avgpool8 * 0.18215), context, x_T."""
     g = torch.Generator(device=device).manual_seed(SEED + 1000 * rank)
@@ -111,12 +127,16 @@ def main():
     from mrisr import _lib as L
     from mrisr import params as P
 
+    log("init weights on device")
     cfg = mrisr.UNetConfig()
     sd = P.random_state_dict(P.unet_param_shapes(cfg), SEED, dev)
     sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), SEED + 3, dev))
     unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype, lora_rank=4, lora_alpha=4,
                                       lora_fused=not args.lora_merged, flash_attention=True)
+    log("load_state_dict + finalize")
     unet.load_state_dict(sd)
+    torch.cuda.synchronize()
+    log("weights packed")
     sched = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
     sched.set_timesteps(N_DDIM)
     sampler = mrisr.Sampler(unet, sched, kind="ddim")
@@ -136,8 +156,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         one_batch()
+        torch.cuda.synchronize()
+        log(f"warmup batch {i} done")
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -147,6 +169,7 @@ def main():
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} batches")
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,6 +195,7 @@ def main():
     lib.mrisr_prof_enable(0)
     classes = prof_report(lib)
     lib.mrisr_prof_reset()
+    log("roofline leg done")
     total_ms = sum(v["ms"] for v in classes.values()) or 1.0
     gemm = {k: v for k, v in classes.items() if k.startswith("gemm_")}
     dom_name = max(gemm, key=lambda k: gemm[k]["ms"]) if gemm else None
@@ -211,7 +235,8 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle import unet as ou
-        threads = os.cpu_count() or 1
+        threads = host_threads()
+        log(f"cpu baseline on {threads} threads")
         sd_cpu = {k: v.detach().float().cpu() for k, v in sd.items()}
         out["cpu_baseline"] = cpu_baseline(sd_cpu, ou.SD15, threads)
     print(json.dumps(out))

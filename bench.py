@@ -228,8 +228,8 @@ def main():
                    "slices_per_gpu_per_step": B, "ddim_steps": N_DDIM, "parallelism": f"slice-sharded x{world} (no collective)",
                    "lora": "merged" if args.lora_merged else "fused rank tail", "hipgraph": not args.no_graph},
         "denoise_step_ms": step_ms,
-        "unet_tflops_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms / 1e3,
-        "frac_of_bf16_peak_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms / 1e3 / PEAK_BF16_TFLOPS,
+        "unet_tflops_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms,
+        "frac_of_bf16_peak_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms / PEAK_BF16_TFLOPS,
         "finite": finite,
         "roofline": roof,
     }

@@ -386,6 +386,7 @@ struct AdRunner {
         }
         if (resid) { g.resid = resid->p; g.ldr = resid->C; }
         g.out = out->p; g.ldo = cw.cout;
+        gemm_set_plan_dtype(sizeof(T) == 2);
         g.splitk = gemm_workspace_splitk(g);
         if (g.splitk > 1) {
             g.partial = static_cast<float*>(a.arena.alloc((size_t)g.splitk * g.M * g.N * sizeof(float)));
@@ -573,6 +574,7 @@ static int op_conv3x3_t(const mrisr_tensor* x, const mrisr_tensor* x2, const flo
     MRISR_REQUIRE(y->shape[1] == cout && y->shape[2] == g.Hout && y->shape[3] == g.Wout, "conv output shape");
     g.w = wp.p; g.M = B * g.Hout * g.Wout; g.N = cout; g.K = 9 * Cin; g.bias = bias; g.act = act;
     g.out = y->data; g.ldo = cout;
+    gemm_set_plan_dtype(sizeof(T) == 2);
     g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
     if (g.splitk > 1) {
         TRY(part.reserve((size_t)g.splitk * g.M * g.N * sizeof(float), false));
@@ -680,6 +682,7 @@ int mrisr_op_linear(const mrisr_tensor* x, const float* w_dev, const float* bias
     GemmArgs g;
     g.a0 = x->data; g.c0 = K; g.lda0 = K; g.w = wp.p; g.M = M; g.N = n; g.K = K; g.bias = bias; g.act = act;
     g.out = y->data; g.ldo = (int)y->shape[1];
+    gemm_set_plan_dtype(!f32);
     g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
     if (g.splitk > 1) {
         TRY(part.reserve((size_t)g.splitk * M * n * sizeof(float), false));
@@ -741,3 +744,67 @@ int mrisr_op_attention(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// GEMM micro-benchmark (tools/gemm_sweep.py): times one implicit-GEMM shape with a forced tile / split-K on
+// pseudo-random operands (zero-filled operands would flatter the clock; guide rule 25).
+// =================================================================================================
+__global__ void fill_random_bf16_kernel(bf16* p, long long n, unsigned seed) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = (bf16)(((float)(x & 0xFFFF) / 32768.0f - 1.0f) * 0.5f);
+    }
+}
+extern "C" void mrisr_debug_force_tile(int t);
+extern "C" int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int W, int stride, int ups, int c1,
+                                int tile, int splitk, int iters, float* ms_out) {
+    API_BEGIN
+    TRY(gemm_prepare());
+    hipStream_t st = nullptr;
+    GemmArgs g;
+    const int Cin = conv ? K / 9 : K;
+    const int c0 = Cin - c1;
+    DevBuf a0, a1, wb, ob, part, bias;
+    const long long a_rows = conv ? (long long)B * H * W : M;
+    TRY(a0.reserve((size_t)a_rows * c0 * 2, false));
+    if (c1) TRY(a1.reserve((size_t)a_rows * c1 * 2, false));
+    TRY(wb.reserve((size_t)N * K * 2, false));
+    TRY(ob.reserve((size_t)M * N * 2, false));
+    TRY(bias.reserve((size_t)N * 4, true));
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(2048), dim3(256), 0, st, (bf16*)a0.p, a_rows * c0, 1u);
+    if (c1) hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(2048), dim3(256), 0, st, (bf16*)a1.p, a_rows * c1, 2u);
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(2048), dim3(256), 0, st, (bf16*)wb.p, (long long)N * K, 3u);
+    g.a0 = a0.p; g.c0 = c0; g.lda0 = c0;
+    if (c1) { g.a1 = a1.p; g.c1 = c1; g.lda1 = c1; }
+    if (conv) {
+        const int Hc = H << ups, Wc = W << ups;
+        g.conv = 1; g.B = B; g.Hin = H; g.Win = W; g.Hout = (Hc - 1) / stride + 1; g.Wout = (Wc - 1) / stride + 1;
+        g.stride = stride; g.ups = ups;
+        MRISR_REQUIRE(M == B * g.Hout * g.Wout, "bench conv M");
+    }
+    g.w = wb.p; g.M = M; g.N = N; g.K = K; g.bias = (const float*)bias.p; g.out = ob.p; g.ldo = N;
+    gemm_set_plan_dtype(true);
+    g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
+    if (g.splitk > 1) {
+        TRY(part.reserve((size_t)g.splitk * M * N * 4, false));
+        g.partial = (float*)part.p;
+    }
+    mrisr_debug_force_tile(tile);
+    for (int i = 0; i < 2; ++i) { int rc = launch_gemm<bf16>(g, st); if (rc) { mrisr_debug_force_tile(0); return rc; } }
+    hipEvent_t e0, e1;
+    MRISR_CHECK_HIP(hipEventCreate(&e0));
+    MRISR_CHECK_HIP(hipEventCreate(&e1));
+    MRISR_CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) (void)launch_gemm<bf16>(g, st);
+    MRISR_CHECK_HIP(hipEventRecord(e1, st));
+    MRISR_CHECK_HIP(hipEventSynchronize(e1));
+    mrisr_debug_force_tile(0);
+    float ms = 0.f;
+    MRISR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return g.splitk * 1000 == 0 ? 0 : 0;
+    API_END
+}

@@ -103,7 +103,8 @@ template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);
 template <typename T> int launch_splitk_reduce(const GemmArgs& g, hipStream_t st);
 const void* zero_page();  // >= 256 bytes of device zeros, valid after init_zero_page()
 int init_zero_page();
-int gemm_prepare();  // set launch attributes of every GEMM instantiation (call before graph capture)
+int gemm_prepare();
+void gemm_set_plan_dtype(bool is_bf16);  // dtype the next gemm_workspace_splitk() calls plan for  // set launch attributes of every GEMM instantiation (call before graph capture)
 
 // ---------------------------------------------------------------------------------------------
 // normalisation (norm.hip)

@@ -357,6 +357,245 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
         }
 }
 
+// =================================================================================================
+// bf16 throughput kernel, buffer-addressed ("bl"): same tiling / LDS image / MFMA orientation as gemm_kernel,
+// but the LDS-DMA goes through buffer descriptors (`buffer_load_dwordx4 ... offen lds`):
+//   address = SGPR base (descriptor) + per-lane VGPR byte offset + SGPR soffset.
+// The per-lane offsets are computed ONCE per (3x3 tap, concat source) segment - for plain rows once per
+// kernel - and the walk along K is a scalar soffset add, so the steady-state loop issues no vector ALU for
+// addressing at all (the 64-bit per-lane address arithmetic of gemm_kernel cost ~3.6 VALU per MFMA and made the
+// loop VALU-issue bound: profiles/r01_pmc_*).  Rows outside the matrix / in the zero padding get an offset
+// beyond num_records: the hardware range check returns zeros, no zero page and no select.
+// =================================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
+#define BL_OOB 0x80000000u
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
+    typedef bf16 T;
+    constexpr int BK = 64;
+    constexpr int A_IT = BM / 32, W_IT = BN / 32;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int MF = WTM / 16, NF = WTN / 16;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WGM * WGN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z;
+    const int split = blockIdx.y;
+
+    const int ntn = (g.N + BN - 1) / BN;
+    const int ntm = (g.M + BM - 1) / BM;
+    const int nblk = ntn * ntm;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = logical % ntn, tm = logical / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const T* a0p = reinterpret_cast<const T*>(g.a0) + (size_t)z * g.a_bs;
+    const T* a1p = reinterpret_cast<const T*>(g.a1);
+    const T* wp = reinterpret_cast<const T*>(g.w) + (size_t)z * g.w_bs;
+    const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)min((long long)g.N * g.K * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(a0p, (unsigned)min(a_rows * g.lda0 * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(a1p ? (const void*)a1p : (const void*)a0p,
+                                                 a1p ? (unsigned)min(a_rows * g.lda1 * 2, 0x7FFFFFFFll) : 0u);
+
+    const int lrow = tid >> 3, pch = tid & 7;
+    unsigned wvo[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int row = it * 32 + lrow;
+        const int n = n0 + row;
+        const int c = pch ^ (row & 7);
+        wvo[it] = n < g.N ? (unsigned)(((size_t)n * g.K + c * 8) * 2) : BL_OOB;
+    }
+    // A rows: byte offsets into the current source for the current segment (plain: fixed for each source)
+    unsigned avo[A_IT], avo1[A_IT];
+    int ab[A_IT], ay[A_IT], ax[A_IT];  // conv: b*Hin, oy*stride-1, ox*stride-1  (ab < 0: row outside the matrix)
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = it * 32 + lrow;
+        const int m = m0 + row;
+        const int c = pch ^ (row & 7);
+        const bool ok = m < g.M;
+        avo[it] = avo1[it] = BL_OOB;
+        ab[it] = -1;
+        ay[it] = ax[it] = 0;
+        if (!g.conv) {
+            if (ok) {
+                avo[it] = (unsigned)(((size_t)m * g.lda0 + c * 8) * 2);
+                avo1[it] = (unsigned)(((size_t)m * g.lda1 + c * 8) * 2);
+            }
+        } else if (ok) {
+            const int hw = g.Hout * g.Wout;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / g.Wout;
+            ab[it] = b * g.Hin;
+            ay[it] = oy * g.stride - 1;
+            ax[it] = (rem - oy * g.Wout) * g.stride - 1;
+        }
+    }
+    const int acb = pch * 16;  // physical chunk byte offset is applied through `c` below for conv rows
+
+    const int nkt = g.K / BK;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int kt_beg = split * per;
+    const int kt_end = min(nkt, kt_beg + per);
+    const int Ct = g.c0 + g.c1;
+    const int Hc = g.Hin << g.ups, Wc = g.Win << g.ups;
+    // conv walk state (uniform): current tap and channel position; seg_key identifies (tap, source)
+    int tap = 0, cc = 0, seg_key = -1;
+    if (g.conv) {
+        const int k0 = kt_beg * BK;
+        tap = k0 / Ct;
+        cc = k0 - tap * Ct;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE;
+        const unsigned k0b = (unsigned)kt * BK * 2;
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, wvo[it], k0b);
+        if (!g.conv) {
+            const bool second = kt * BK >= g.c0;
+            if (!second) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) bl16(ra0, sb + (it * 256 + wave * 64) * 16, avo[it], k0b);
+            } else {
+                const unsigned kb = (unsigned)(kt * BK - g.c0) * 2;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) bl16(ra1, sb + (it * 256 + wave * 64) * 16, avo1[it], kb);
+            }
+        } else {
+            const bool second = cc >= g.c0;
+            const int key = tap * 2 + (second ? 1 : 0);
+            if (key != seg_key) {  // new (tap, source) segment: refresh the per-lane offsets (uniform branch)
+                seg_key = key;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int ld = second ? g.lda1 : g.lda0;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const int row = it * 32 + lrow;
+                    const int c = pch ^ (row & 7);
+                    const int iy = ay[it] + ky, ix = ax[it] + kx;
+                    const bool ok = ab[it] >= 0 && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+                    const unsigned pix = (unsigned)((ab[it] + (iy >> g.ups)) * g.Win + (ix >> g.ups));
+                    avo[it] = ok ? (pix * (unsigned)ld + (unsigned)c * 8u) * 2u : BL_OOB;
+                }
+            }
+            const unsigned chb = (unsigned)(second ? cc - g.c0 : cc) * 2;
+            if (!second) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) bl16(ra0, sb + (it * 256 + wave * 64) * 16, avo[it], chb);
+            } else {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) bl16(ra1, sb + (it * 256 + wave * 64) * 16, avo[it], chb);
+            }
+            cc += BK;
+            if (cc >= Ct) { cc = 0; ++tap; }
+        }
+    };
+    (void)acb;
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm0 = (wave / WGN) * WTM, wn0 = (wave % WGN) * WTN;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE;
+        const char* sw = sa + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int phys = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            bf16x8 wf[NF], af[MF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sw + (wn0 + i * 16 + fr) * 128 + phys);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + (wm0 + j * 16 + fr) * 128 + phys);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (kt_beg < kt_end) {
+        stage(kt_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    if (g.splitk > 1) {
+        float* part = g.partial + ((size_t)z * g.splitk + split) * (size_t)g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wm0 + j * 16 + fr;
+                const int n = n0 + wn0 + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4<float>(part + (size_t)m * g.N + n, v);
+                }
+            }
+        return;
+    }
+    if (g.act == ACT_GEGLU) {
+#pragma unroll
+        for (int i = 0; i < NF; i += 2)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wm0 + j * 16 + fr;
+                const int n = n0 + wn0 + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    float vg[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
+                    epilogue4<T>(g, z, m, n, v, vg);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wm0 + j * 16 + fr;
+            const int n = n0 + wn0 + i * 16 + fg * 4;
+            if (m < g.M && n < g.N) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue4<T>(g, z, m, n, v, nullptr);
+            }
+        }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const int nq = g.N >> 2;
@@ -397,13 +636,6 @@ static int prepare_all() {
     if (prepare_cfg<T, 64, 64, 2, 2>()) return 1;
     return 0;
 }
-// Raise the dynamic-LDS limit of every GEMM instantiation up front (never inside a stream capture).
-int gemm_prepare() {
-    if (init_zero_page()) return 1;
-    if (prepare_all<float>()) return 1;
-    return prepare_all<bf16>();
-}
-
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * 128;
@@ -426,30 +658,113 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
-static int g_force_tile = 0;  // test hook: 0 auto, 1..4 fixed config
+static int g_force_tile = 0;  // test hook: 0 auto, 1..4 small-kernel configs, 5..9 ring-kernel configs
 extern "C" void mrisr_debug_force_tile(int t) { g_force_tile = t; }
 
-static int pick_tile(const GemmArgs& g) {
-    if (g_force_tile) return g_force_tile;
-    if (g.act == ACT_GEGLU) return 1;                 // needs NF even and >= 2 per wave: 128x128 (NF=4)
-    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
-    if (g.N % 128 != 0 && g.N % 64 == 0 && g.M >= 4096) return 2;   // e.g. N = 320: 256x64 tiles, no N waste
-    if (g.N <= 64) return (g.M >= 4096) ? 2 : 4;
-    if (t128 < 128) return 4;                         // tiny problems: 64x64 tiles for more blocks
-    return 1;
+template <int BM, int BN, int WGM, int WGN>
+static int prepare_bl() {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool done = false;
+    if (!done) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bl_kernel<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        done = true;
+    }
+    return 0;
+}
+template <int BM, int BN, int WGM, int WGN>
+static int launch_bl(const GemmArgs& g, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    if (prepare_bl<BM, BN, WGM, WGN>()) return 1;
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    dim3 grid(ntn * ntm, g.splitk, g.batch);
+    static const std::string pname = std::string("gemm_bf16_bl") + std::to_string(BM) + "x" + std::to_string(BN);
+    double fl = g.alg_flops, by = g.alg_bytes;
+    if (prof_enabled()) {
+        if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K * g.batch;
+        if (by == 0.0) {
+            const double a_el = g.conv ? (double)g.B * g.Hin * g.Win * (g.c0 + g.c1) : (double)g.M * g.K;
+            by = 2.0 * g.batch * (a_el + (double)g.N * g.K + (double)g.M * g.N);
+        }
+    }
+    ProfScope ps(pname.c_str(), fl, by, st);
+    hipLaunchKernelGGL((gemm_bl_kernel<BM, BN, WGM, WGN>), grid, dim3(256), smem, st, g);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// buffer-addressed configurations: id -> <BM, BN, WGM, WGN>
+#define BL_CFGS(X)          \
+    X(14, 128, 128, 2, 2)   \
+    X(15, 256, 64, 4, 1)    \
+    X(16, 128, 64, 2, 2)    \
+    X(17, 64, 64, 2, 2)     \
+    X(18, 64, 128, 2, 2)
+static int prepare_bls() {
+#define X(id, bm, bn, wm, wn) if (prepare_bl<bm, bn, wm, wn>()) return 1;
+    BL_CFGS(X)
+#undef X
+    return 0;
+}
+// buffer descriptors address at most 2^31 bytes per operand
+static bool bl_ok(const GemmArgs& g) {
+    const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
+    const long long lim = 0x7FFFFFFFll;
+    return a_rows * g.lda0 * 2 < lim && a_rows * (long long)g.lda1 * 2 < lim && (long long)g.N * g.K * 2 < lim;
 }
 
+// ---- tile / split-K planner ------------------------------------------------------------------
+struct TileCfg { int id, bm, bn; double eff; bool bl; };
+// eff: relative main-loop efficiency measured with tools/gemm_sweep.py (profiles/r01_gemm_sweep.log)
+static const TileCfg kTiles[] = {
+    {14, 128, 128, 1.00, true}, {15, 256, 64, 0.90, true}, {16, 128, 64, 0.88, true}, {18, 64, 128, 0.86, true},
+    {17, 64, 64, 0.60, true},
+    {1, 128, 128, 0.75, false}, {2, 256, 64, 0.65, false}, {3, 128, 64, 0.60, false}, {4, 64, 64, 0.45, false},
+};
+static double g_tile_eff[32] = {0};
+extern "C" void mrisr_debug_set_tile_eff(int id, double eff) { if (id >= 0 && id < 32) g_tile_eff[id] = eff; }
+
+// cost model: rounds of (2 workgroups x 256 CUs) x time of one workgroup (MFMA work / efficiency + fixed prologue /
+// epilogue latency), plus the split-K slab traffic.  Only the ranking matters.
+static void plan(const GemmArgs& g, bool is_bf16, int fixed_split, int* tile_out, int* split_out) {
+    const double cu_flops = 1.0e15 / 256.0 * 1e-6;  // FLOP per microsecond per CU at the kernel's practical rate
+    double best = 1e300;
+    int bt = is_bf16 ? 14 : 1, bs = 1;
+    const int nkt = g.K / (is_bf16 ? 64 : 32);
+    const bool use_bl = is_bf16 && bl_ok(g);
+    for (const TileCfg& t : kTiles) {
+        if (t.bl != use_bl) continue;
+        const double eff = g_tile_eff[t.id] > 0 ? g_tile_eff[t.id] : t.eff;
+        const long long tiles = (long long)((g.M + t.bm - 1) / t.bm) * ((g.N + t.bn - 1) / t.bn) * g.batch;
+        for (int s = 1; s <= 32; s *= 2) {
+            if (fixed_split > 0 && s != fixed_split) continue;
+            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 6)) break;
+            const long long blocks = tiles * s;
+            const long long rounds = (blocks + 511) / 512;
+            const double wg_us = 2.0 * t.bm * t.bn * ((double)g.K / s) / (cu_flops * eff) * 2.0 + 4.0;
+            double cost = rounds * wg_us;
+            if (s > 1) cost += 2.0 + (double)g.M * g.N * g.batch * (4.0 * s * 2 + 2) / 3.0e6;  // slab write+read
+            if (cost < best) { best = cost; bt = t.id; bs = s; }
+        }
+    }
+    if (fixed_split > 0 && best >= 1e300) bs = fixed_split;
+    *tile_out = bt;
+    *split_out = bs;
+}
+
+static bool g_plan_bf16 = true;  // gemm_workspace_splitk has no T: the Runner sets the dtype it plans for
+void gemm_set_plan_dtype(bool is_bf16) { g_plan_bf16 = is_bf16; }
+
 int gemm_workspace_splitk(const GemmArgs& g) {
-    // split K when the 128x128 tiling leaves most of the 256 CUs idle and K is deep
-    const int bk = 64;
-    const long long tiles = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
-    const int nkt = g.K / bk;
-    if (g.act == ACT_GEGLU) return 1;
-    if (tiles >= 192 || nkt < 16) return 1;
-    int s = (int)((384 + tiles - 1) / tiles);
-    if (s > nkt / 8) s = nkt / 8;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
+    if (g_force_tile) return g.splitk > 0 ? g.splitk : 1;
+    int t, s;
+    plan(g, g_plan_bf16, 0, &t, &s);
+    return s;
+}
+
+int gemm_prepare() {
+    if (init_zero_page()) return 1;
+    if (prepare_all<float>()) return 1;
+    if (prepare_all<bf16>()) return 1;
+    return prepare_bls();
 }
 
 template <typename T>
@@ -463,11 +778,17 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     MRISR_REQUIRE(zero_page() != nullptr, "zero page not initialised");
     if (g.conv) MRISR_REQUIRE(g.K == 9 * (g.c0 + g.c1), "conv K");
     else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
+    int tile = g_force_tile, s = g.splitk;
+    if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
+    if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;
     int rc;
-    switch (pick_tile(g)) {
+    switch (tile) {
         case 2: rc = launch_cfg<T, 256, 64, 4, 1>(g, st); break;
         case 3: rc = launch_cfg<T, 128, 64, 2, 2>(g, st); break;
         case 4: rc = launch_cfg<T, 64, 64, 2, 2>(g, st); break;
+#define X(id, bm, bn, wm, wn) case id: rc = launch_bl<bm, bn, wm, wn>(g, st); break;
+        BL_CFGS(X)
+#undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
     }
     if (rc) return rc;

@@ -387,6 +387,7 @@ struct Runner {
     }
 
     int run_gemm(GemmArgs& g) {
+        gemm_set_plan_dtype(sizeof(T) == 2);
         g.splitk = gemm_workspace_splitk(g);
         if (g.splitk > 1) {
             g.partial = static_cast<float*>(alloc((size_t)g.splitk * g.batch * g.M * g.N * sizeof(float)));

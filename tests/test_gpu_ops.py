@@ -135,3 +135,45 @@ def test_attention_flash_online_softmax_rescale_branch():
     ref = _sdpa(q, k, v, H)
     y = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, flash=True)
     assert rel(y, ref) < 2e-2
+
+
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18])
+@pytest.mark.parametrize("M,N,K,splitk", [(512, 320, 256, 1), (1000, 640, 384, 1), (256, 1280, 2048, 4), (300, 68, 192, 1),
+                                          (4096, 960, 384, 1), (130, 320, 64, 1)])
+def test_linear_buffer_addressed_kernel(tile, M, N, K, splitk):
+    """The buffer-addressed bf16 kernel (descriptor + per-lane offset + scalar K walk): every tile shape, ragged M/N, split-K, and
+    K as short as one K tile."""
+    from mrisr import ops
+    x, w, b = _rnd((M, K), "bf16", 31), _rnd((N, K), "f32", 32, K ** -0.5), _rnd((N,), "f32", 33)
+    ref = F.linear(x.float(), w.to(torch.bfloat16).float(), b)
+    y = ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=tile, splitk=splitk)
+    assert rel(y, ref) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18])
+@pytest.mark.parametrize("B,Cin,Cout,H,stride,ups,splitk", [(2, 64, 320, 16, 1, False, 1), (1, 320, 320, 32, 1, False, 1),
+                                                            (2, 128, 64, 8, 1, True, 1), (2, 64, 128, 16, 2, False, 1),
+                                                            (3, 256, 256, 4, 1, False, 4), (1, 64, 64, 5, 1, False, 1)])
+def test_conv3x3_buffer_addressed_kernel(tile, B, Cin, Cout, H, stride, ups, splitk):
+    from mrisr import ops
+    x = _rnd((B, Cin, H, H), "bf16", 34)
+    w, b = _rnd((Cout, Cin, 3, 3), "f32", 35, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 36)
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xi, w.to(torch.bfloat16).float(), b, stride=stride, padding=1)
+    y = ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), stride=stride, upsample=ups, tile=tile, splitk=splitk)
+    assert rel(y, ref) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18])
+def test_buffer_addressed_kernel_concat_and_geglu(tile):
+    from mrisr import _lib as L
+    from mrisr import ops
+    x1, x2 = _rnd((2, 128, 8, 8), "bf16", 37), _rnd((2, 64, 8, 8), "bf16", 38)
+    w, b = _rnd((128, 192, 3, 3), "f32", 39, (9 * 192) ** -0.5), _rnd((128,), "f32", 40)
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), w.to(torch.bfloat16).float(), b, padding=1)
+    assert rel(ops.conv3x3(x1.cuda(), w.cuda(), b.cuda(), x2=x2.cuda(), tile=tile), ref) < TOL["bf16"]
+    M, Cc = 384, 128
+    x, wg, bg = _rnd((M, Cc), "bf16", 41), _rnd((8 * Cc, Cc), "f32", 42, Cc ** -0.5), _rnd((8 * Cc,), "f32", 43)
+    h = F.linear(x.float(), wg.to(torch.bfloat16).float(), bg)
+    u, g = h.chunk(2, dim=-1)
+    assert rel(ops.linear(x.cuda(), wg.cuda(), bg.cuda(), act=L.ACT_GEGLU, tile=tile), u * F.gelu(g)) < TOL["bf16"]

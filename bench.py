@@ -73,7 +73,7 @@ def synthetic_batch(B, device, rank):
 
 
 def prof_report(lib):
-    buf = C.create_string_buffer(1 << 16)
+    buf = C.create_string_buffer(1 << 20)
     n = lib.mrisr_prof_report(buf, len(buf))
     return json.loads(buf.value.decode()) if n > 0 else {}
 

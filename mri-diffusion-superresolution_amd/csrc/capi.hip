@@ -386,8 +386,7 @@ struct AdRunner {
         }
         if (resid) { g.resid = resid->p; g.ldr = resid->C; }
         g.out = out->p; g.ldo = cw.cout;
-        gemm_set_plan_dtype(sizeof(T) == 2);
-        g.splitk = gemm_workspace_splitk(g);
+        TRY(gemm_choose(g, sizeof(T) == 2));
         if (g.splitk > 1) {
             g.partial = static_cast<float*>(a.arena.alloc((size_t)g.splitk * g.M * g.N * sizeof(float)));
             if (!g.partial) return 7;
@@ -574,8 +573,8 @@ static int op_conv3x3_t(const mrisr_tensor* x, const mrisr_tensor* x2, const flo
     MRISR_REQUIRE(y->shape[1] == cout && y->shape[2] == g.Hout && y->shape[3] == g.Wout, "conv output shape");
     g.w = wp.p; g.M = B * g.Hout * g.Wout; g.N = cout; g.K = 9 * Cin; g.bias = bias; g.act = act;
     g.out = y->data; g.ldo = cout;
-    gemm_set_plan_dtype(sizeof(T) == 2);
-    g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
+    g.splitk = splitk;
+    if (splitk <= 0) { g.splitk = 1; TRY(gemm_choose(g, sizeof(T) == 2)); }
     if (g.splitk > 1) {
         TRY(part.reserve((size_t)g.splitk * g.M * g.N * sizeof(float), false));
         g.partial = static_cast<float*>(part.p);
@@ -682,8 +681,8 @@ int mrisr_op_linear(const mrisr_tensor* x, const float* w_dev, const float* bias
     GemmArgs g;
     g.a0 = x->data; g.c0 = K; g.lda0 = K; g.w = wp.p; g.M = M; g.N = n; g.K = K; g.bias = bias; g.act = act;
     g.out = y->data; g.ldo = (int)y->shape[1];
-    gemm_set_plan_dtype(!f32);
-    g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
+    g.splitk = splitk;
+    if (splitk <= 0) { g.splitk = 1; mrisr_debug_force_tile(tile); TRY(gemm_choose(g, !f32)); }
     if (g.splitk > 1) {
         TRY(part.reserve((size_t)g.splitk * M * n * sizeof(float), false));
         g.partial = static_cast<float*>(part.p);
@@ -784,8 +783,8 @@ extern "C" int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int
         MRISR_REQUIRE(M == B * g.Hout * g.Wout, "bench conv M");
     }
     g.w = wb.p; g.M = M; g.N = N; g.K = K; g.bias = (const float*)bias.p; g.out = ob.p; g.ldo = N;
-    gemm_set_plan_dtype(true);
-    g.splitk = splitk > 0 ? splitk : gemm_workspace_splitk(g);
+    g.splitk = splitk;
+    if (splitk <= 0) { g.splitk = 1; mrisr_debug_force_tile(tile); TRY(gemm_choose(g, true)); }
     if (g.splitk > 1) {
         TRY(part.reserve((size_t)g.splitk * M * N * 4, false));
         g.partial = (float*)part.p;

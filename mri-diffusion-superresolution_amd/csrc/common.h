@@ -96,15 +96,15 @@ struct GemmArgs {
     int secC = 0, hd = 0, dpad = 0, ntok = 0, npad = 0, nheads = 0;
     // profiler only: algorithmic work of this launch (0 -> derived from M, N, K)
     double alg_flops = 0.0, alg_bytes = 0.0;
+    int tile = 0;  // kernel configuration chosen by gemm_choose (0: let launch_gemm plan)
 };
 
-int gemm_workspace_splitk(const GemmArgs& g);  // recommended split (1 = none)
 template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);
 template <typename T> int launch_splitk_reduce(const GemmArgs& g, hipStream_t st);
 const void* zero_page();  // >= 256 bytes of device zeros, valid after init_zero_page()
 int init_zero_page();
 int gemm_prepare();
-void gemm_set_plan_dtype(bool is_bf16);  // dtype the next gemm_workspace_splitk() calls plan for  // set launch attributes of every GEMM instantiation (call before graph capture)
+int gemm_choose(GemmArgs& g, bool is_bf16);  // sets g.tile / g.splitk (autotuned per signature for bf16)  // set launch attributes of every GEMM instantiation (call before graph capture)
 
 // ---------------------------------------------------------------------------------------------
 // normalisation (norm.hip)

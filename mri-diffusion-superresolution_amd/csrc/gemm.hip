@@ -15,6 +15,9 @@
 #include "common.h"
 #include "prof.h"
 
+#include <cstdlib>
+#include <map>
+
 namespace mrisr {
 
 static void* g_zero_page = nullptr;
@@ -376,7 +379,11 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 }
 #define BL_OOB 0x80000000u
 
-template <int BM, int BN, int WGM, int WGN>
+// NSTAGE = 2: double buffer, one drain + barrier per K tile - best when >= 2 workgroups share a CU and hide each
+// other's load latency.  NSTAGE > 2: an LDS ring with NSTAGE-1 tiles of LDS-DMA in flight behind a counted
+// `s_waitcnt vmcnt(N)` and a raw `s_barrier` - for shapes with too few tiles to give every CU two workgroups
+// (small M / deep K), where the 2-stage loop is bound by one exposed load latency per K tile.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
     typedef bf16 T;
     constexpr int BK = 64;
@@ -469,6 +476,15 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
     auto stage = [&](int kt, int buf) {
         char* sb = smem + buf * STAGE;
         const unsigned k0b = (unsigned)kt * BK * 2;
+        if (NSTAGE > 2 && kt >= kt_end) {
+            // past the end of this split: keep every wave's DMA count constant (the counted vmcnt depends on it);
+            // out-of-range offsets are dropped to zeros by the descriptor's range check
+#pragma unroll
+            for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, BL_OOB, 0);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) bl16(ra0, sb + (it * 256 + wave * 64) * 16, BL_OOB, 0);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, wvo[it], k0b);
         if (!g.conv) {
@@ -661,23 +677,30 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
 static int g_force_tile = 0;  // test hook: 0 auto, 1..4 small-kernel configs, 5..9 ring-kernel configs
 extern "C" void mrisr_debug_force_tile(int t) { g_force_tile = t; }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 static int prepare_bl() {
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = NSTAGE * (BM + BN) * 128;
     static bool done = false;
     if (!done) {
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bl_kernel<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         done = true;
     }
     return 0;
 }
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 static int launch_bl(const GemmArgs& g, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * 128;
-    if (prepare_bl<BM, BN, WGM, WGN>()) return 1;
+    constexpr int smem = NSTAGE * (BM + BN) * 128;
+    if (prepare_bl<BM, BN, WGM, WGN, NSTAGE>()) return 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     dim3 grid(ntn * ntm, g.splitk, g.batch);
-    static const std::string pname = std::string("gemm_bf16_bl") + std::to_string(BM) + "x" + std::to_string(BN);
+    static const std::string base_name = std::string("gemm_bf16_bl") + std::to_string(BM) + "x" + std::to_string(BN) + (NSTAGE > 2 ? "d" + std::to_string(NSTAGE) : std::string());
+    std::string pname = base_name;
+    if (prof_enabled() && prof_shapes()) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s %s M=%d N=%d K=%d s=%d b=%d", base_name.c_str(), g.conv ? (g.ups ? "convup" : (g.stride == 2 ? "convs2" : "conv")) : "lin",
+                 g.M, g.N, g.K, g.splitk, g.batch);
+        pname = buf;
+    }
     double fl = g.alg_flops, by = g.alg_bytes;
     if (prof_enabled()) {
         if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K * g.batch;
@@ -686,20 +709,26 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
             by = 2.0 * g.batch * (a_el + (double)g.N * g.K + (double)g.M * g.N);
         }
     }
-    ProfScope ps(pname.c_str(), fl, by, st);
-    hipLaunchKernelGGL((gemm_bl_kernel<BM, BN, WGM, WGN>), grid, dim3(256), smem, st, g);
+    ProfScope ps(prof_intern(pname), fl, by, st);
+    hipLaunchKernelGGL((gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE>), grid, dim3(256), smem, st, g);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
 // buffer-addressed configurations: id -> <BM, BN, WGM, WGN>
-#define BL_CFGS(X)          \
-    X(14, 128, 128, 2, 2)   \
-    X(15, 256, 64, 4, 1)    \
-    X(16, 128, 64, 2, 2)    \
-    X(17, 64, 64, 2, 2)     \
-    X(18, 64, 128, 2, 2)
+#define BL_CFGS(X)             \
+    X(14, 128, 128, 2, 2, 2)   \
+    X(15, 256, 64, 4, 1, 2)    \
+    X(16, 128, 64, 2, 2, 2)    \
+    X(17, 64, 64, 2, 2, 2)     \
+    X(18, 64, 128, 2, 2, 2)    \
+    X(19, 128, 128, 2, 2, 4)   \
+    X(20, 128, 64, 2, 2, 4)    \
+    X(21, 64, 128, 2, 2, 4)    \
+    X(22, 64, 64, 2, 2, 4)     \
+    X(23, 128, 128, 2, 2, 3)   \
+    X(24, 256, 64, 4, 1, 3)
 static int prepare_bls() {
-#define X(id, bm, bn, wm, wn) if (prepare_bl<bm, bn, wm, wn>()) return 1;
+#define X(id, bm, bn, wm, wn, ns) if (prepare_bl<bm, bn, wm, wn, ns>()) return 1;
     BL_CFGS(X)
 #undef X
     return 0;
@@ -750,14 +779,139 @@ static void plan(const GemmArgs& g, bool is_bf16, int fixed_split, int* tile_out
     *split_out = bs;
 }
 
-static bool g_plan_bf16 = true;  // gemm_workspace_splitk has no T: the Runner sets the dtype it plans for
-void gemm_set_plan_dtype(bool is_bf16) { g_plan_bf16 = is_bf16; }
+// ---- plan-time autotuner ------------------------------------------------------------------------
+// The first time a GEMM signature is planned (during the dry pass that sizes a model's workspace - never inside a
+// stream capture) every admissible (tile, stages, split-K) candidate is timed on scratch operands of the real
+// shape and the winner is cached for the life of the process.  MRISR_AUTOTUNE=0 falls back to the cost model.
+__global__ void tune_fill_kernel(bf16* p, long long n, unsigned seed) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = (bf16)(((float)(x & 0xFFFF) / 32768.0f - 1.0f) * 0.5f);
+    }
+}
+struct TuneScratch {
+    void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[6] = {0, 0, 0, 0, 0, 0};
+    int reserve(int i, size_t bytes, bool randomize) {
+        if (bytes <= cap[i]) return 0;
+        if (p[i]) (void)hipFree(p[i]);
+        p[i] = nullptr; cap[i] = 0;
+        bytes = (bytes + (1 << 20)) & ~(size_t)((1 << 20) - 1);
+        MRISR_CHECK_HIP(hipMalloc(&p[i], bytes));
+        cap[i] = bytes;
+        if (randomize) hipLaunchKernelGGL(tune_fill_kernel, dim3(2048), dim3(256), 0, nullptr, (bf16*)p[i], (long long)(bytes / 2), 17u + i);
+        else MRISR_CHECK_HIP(hipMemset(p[i], 0, bytes));
+        return 0;
+    }
+    void release() {
+        for (int i = 0; i < 6; ++i) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+    }
+};
+static TuneScratch g_ts;
+static std::map<std::string, std::pair<int, int>> g_tuned;
+static int g_tune_count = 0;
+static double g_tune_ms = 0.0;
+extern "C" int mrisr_autotune_stats(int* shapes, double* ms) { if (shapes) *shapes = g_tune_count; if (ms) *ms = g_tune_ms; return 0; }
+extern "C" void mrisr_autotune_release(void) { g_ts.release(); }
 
-int gemm_workspace_splitk(const GemmArgs& g) {
-    if (g_force_tile) return g.splitk > 0 ? g.splitk : 1;
-    int t, s;
-    plan(g, g_plan_bf16, 0, &t, &s);
-    return s;
+static bool autotune_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRISR_AUTOTUNE"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+int mrisr_prof_enable_internal(int on);
+
+template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);
+
+static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
+    char key[200];
+    snprintf(key, sizeof(key), "%d,%d,%d,c%d,s%d,u%d,%d,%d,a%d,o%d,b%d,r%d,v%d,h%d,w%d", g0.M, g0.N, g0.K, g0.conv, g0.stride, g0.ups, g0.c0,
+             g0.c1, g0.act, g0.out_mode, g0.batch, g0.resid ? 1 : 0, g0.rowvec ? 1 : 0, g0.Hin, g0.Win);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) { *tile_out = it->second.first; *split_out = it->second.second; return 0; }
+    // scratch operands
+    GemmArgs g = g0;
+    const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
+    const size_t zb = (size_t)(g.batch > 1 ? g.batch : 1);
+    if (g_ts.reserve(0, (size_t)a_rows * g.lda0 * 2 * zb + 4096, true)) return 1;
+    if (g.c1 && g_ts.reserve(1, (size_t)a_rows * g.lda1 * 2 + 4096, true)) return 1;
+    if (g_ts.reserve(2, (size_t)g.N * g.K * 2 * zb + 4096, true)) return 1;
+    if (g_ts.reserve(3, (size_t)g.M * g.N * 4 * zb + 4096, false)) return 1;
+    if (g_ts.reserve(5, (size_t)(g.N + 64) * 4 + ((size_t)(g.rowvec ? g.M / (g.rowvec_div > 0 ? g.rowvec_div : 1) + 1 : 1)) * (g.N + 64) * 4, false)) return 1;
+    g.a0 = g_ts.p[0]; g.a_bs = g.batch > 1 ? (long long)a_rows * g.lda0 : 0;
+    g.a1 = g.c1 ? g_ts.p[1] : nullptr;
+    g.w = g_ts.p[2]; g.w_bs = g.batch > 1 ? (long long)g.N * g.K : 0;
+    g.bias = g.bias ? (const float*)g_ts.p[5] : nullptr;
+    if (g.rowvec) { g.rowvec = (const float*)g_ts.p[5] + g.N + 64; g.rowvec_ld = g.N + 64; }
+    g.heads = 1; g.o_hs = 0; g.o_bs = g.batch > 1 ? (long long)g.M * g.N : 0;
+    if (g.out_mode == OUT_HEADS) g.out_mode = OUT_ROWS;
+    g.out = g_ts.p[3]; g.ldo = g.act == ACT_GEGLU ? g.N / 2 : g.N;
+    if (g.resid) { g.resid = g_ts.p[3]; g.ldr = g.ldo; }
+    const int nkt = g.K / 64;
+    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    double best = 1e30;
+    int bt = 14, bs = 1;
+    hipEvent_t e0, e1;
+    MRISR_CHECK_HIP(hipEventCreate(&e0));
+    MRISR_CHECK_HIP(hipEventCreate(&e1));
+    const bool prof_was = prof_enabled();
+    mrisr_prof_enable_internal(0);
+    hipEvent_t t0, t1;
+    MRISR_CHECK_HIP(hipEventCreate(&t0));
+    MRISR_CHECK_HIP(hipEventCreate(&t1));
+    MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
+    static const int cand[] = {14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
+    for (int tile : cand) {
+        const bool deep = tile >= 19;
+        if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
+        for (int s = 1; s <= 32; s *= 2) {
+            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096)) break;
+            const size_t pbytes = s > 1 ? (size_t)s * g.M * g.N * 4 * zb : 0;
+            if (pbytes > ((size_t)1 << 30)) break;
+            if (s > 1 && g_ts.reserve(4, pbytes, false)) return 1;
+            g.splitk = s;
+            g.partial = s > 1 ? (float*)g_ts.p[4] : nullptr;
+            g.tile = tile;
+            if (launch_gemm<bf16>(g, nullptr)) return 1;  // warm-up
+            MRISR_CHECK_HIP(hipEventRecord(e0, nullptr));
+            const int iters = 3;
+            for (int i = 0; i < iters; ++i) (void)launch_gemm<bf16>(g, nullptr);
+            MRISR_CHECK_HIP(hipEventRecord(e1, nullptr));
+            MRISR_CHECK_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            MRISR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (ms / iters < best) { best = ms / iters; bt = tile; bs = s; }
+        }
+    }
+    MRISR_CHECK_HIP(hipEventRecord(t1, nullptr));
+    MRISR_CHECK_HIP(hipEventSynchronize(t1));
+    float tms = 0.f;
+    (void)hipEventElapsedTime(&tms, t0, t1);
+    g_tune_ms += tms;
+    ++g_tune_count;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    mrisr_prof_enable_internal(prof_was ? 1 : 0);
+    g_tuned[key] = {bt, bs};
+    *tile_out = bt;
+    *split_out = bs;
+    return 0;
+}
+
+// Chooses tile + split-K for g (sets g.tile / g.splitk).  Deterministic per signature within a process.
+int gemm_choose(GemmArgs& g, bool is_bf16) {
+    int t = 0, s = 1;
+    if (g_force_tile) { g.tile = g_force_tile; if (g.splitk < 1) g.splitk = 1; return 0; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (is_bf16 && bl_ok(g) && autotune_enabled()) {
+        if (tune(g, &t, &s)) return 1;
+    } else {
+        plan(g, is_bf16, 0, &t, &s);
+    }
+    (void)cs;
+    g.tile = t;
+    g.splitk = s;
+    return 0;
 }
 
 int gemm_prepare() {
@@ -778,7 +932,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     MRISR_REQUIRE(zero_page() != nullptr, "zero page not initialised");
     if (g.conv) MRISR_REQUIRE(g.K == 9 * (g.c0 + g.c1), "conv K");
     else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
-    int tile = g_force_tile, s = g.splitk;
+    int tile = g.tile ? g.tile : g_force_tile, s = g.splitk;
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
     if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;
     int rc;
@@ -786,7 +940,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         case 2: rc = launch_cfg<T, 256, 64, 4, 1>(g, st); break;
         case 3: rc = launch_cfg<T, 128, 64, 2, 2>(g, st); break;
         case 4: rc = launch_cfg<T, 64, 64, 2, 2>(g, st); break;
-#define X(id, bm, bn, wm, wn) case id: rc = launch_bl<bm, bn, wm, wn>(g, st); break;
+#define X(id, bm, bn, wm, wn, ns) case id: rc = launch_bl<bm, bn, wm, wn, ns>(g, st); break;
         BL_CFGS(X)
 #undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;

@@ -2,9 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 namespace mrisr {
 
 bool prof_enabled();
+bool prof_shapes();                          // MRISR_PROF_SHAPES=1: GEMM scopes are named per shape
+const char* prof_intern(const std::string& s);  // stable storage for dynamic scope names
 struct ProfScope {
     int idx = -1;
     hipStream_t st;

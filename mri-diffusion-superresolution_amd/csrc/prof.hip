@@ -2,6 +2,7 @@
 #include "prof.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -21,6 +22,18 @@ static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 
 bool prof_enabled() { return g_on; }
+bool prof_shapes() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MRISR_PROF_SHAPES");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+const char* prof_intern(const std::string& s) {
+    static std::map<std::string, int> pool;
+    return pool.emplace(s, 0).first->first.c_str();
+}
 
 static hipEvent_t get_event() {
     if (!g_pool.empty()) {
@@ -48,6 +61,7 @@ ProfScope::~ProfScope() {
 
 }  // namespace mrisr
 
+namespace mrisr { int mrisr_prof_enable_internal(int on) { g_on = on != 0; return 0; } }
 using namespace mrisr;
 
 extern "C" {

@@ -23,11 +23,11 @@ __device__ __forceinline__ float xor_sum(float v) {
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
 
-template <int DPAD, int QF>
+template <int DPAD, int DB, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int KT = 64;                  // keys per LDS tile
     constexpr int KSTEPS = DPAD / 32;       // MFMA k-steps over the head dim for S
-    constexpr int DB = DPAD / 16;           // 16-row blocks of O^T
+    // DB: 16-row blocks of O^T actually needed = ceil(hd / 16)  (hd = 40 -> 3 of the 4 in DPAD = 64)
     constexpr int KP = DPAD * 2 + 16;       // K tile row pitch (bytes), padded
     constexpr int VP = KT * 2 + 16;         // V^T tile row pitch (bytes), padded
     constexpr int CPT = DPAD / 32;          // 16-byte chunks per thread per tile (K and V^T alike)
@@ -101,53 +101,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         commit();
         __syncthreads();
         if (t + 1 < ntiles) fetch(kt0 + KT);
+        // ---- S^T for 64 keys x (QF*16) queries: 4 key blocks of 16 ----
+        f32x4 s[QF][4];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) s[f][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], s[f][tt], 0, 0, 0);
+            }
+        }
+        const bool ragged = kt0 + KT > a.nk;  // only the last tile can hold masked keys (uniform branch)
+        // ---- online softmax, once per 64 keys: lane owns q = fr; its 16 values are keys 16tt + 4fg + r ----
+        bf16x8 pf[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            if (ragged) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt0 + tt * 16 + fg * 4 + r >= a.nk) s[f][tt][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
+#pragma unroll
+            for (int tt = 1; tt < 4; ++tt) mx = fmaxf(mx, fmaxf(fmaxf(s[f][tt][0], s[f][tt][1]), fmaxf(s[f][tt][2], s[f][tt][3])));
+            mx = xor_max(mx) * sl2;                       // running max kept in the scaled (log2) domain
+            const float m_new = fmaxf(m_run[f], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+            m_run[f] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[f][tt][r], sl2, -m_new));  // exp(scale*(s - max))
+                    ps += p;
+                    pf[f][tt >> 1][(tt & 1) * 4 + r] = (bf16)p;
+                }
+            l_run[f] = l_run[f] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
+        }
+        // ---- O^T += V^T . P^T : two 32-key steps ----
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            if (kt0 + sub * 32 >= a.nk) break;  // uniform
-            // ---- S^T for 32 keys x (QF*16) queries ----
-            f32x4 s[QF][2];
-#pragma unroll
-            for (int f = 0; f < QF; ++f) s[f][0] = s[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + (sub * 32 + tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
-#pragma unroll
-                    for (int f = 0; f < QF; ++f) s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], s[f][tt], 0, 0, 0);
-                }
-            }
-            // ---- online softmax: lane owns q = fr; its 8 values are keys 4fg+r and 16+4fg+r ----
-            bf16x8 pf[QF];
-#pragma unroll
-            for (int f = 0; f < QF; ++f) {
-                float v[8];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt0 + sub * 32 + tt * 16 + fg * 4 + r;
-                        const float x = key < a.nk ? s[f][tt][r] * sl2 : -INFINITY;
-                        v[tt * 4 + r] = x;
-                        mx = fmaxf(mx, x);
-                    }
-                mx = xor_max(mx);
-                const float m_new = fmaxf(m_run[f], mx);
-                const float alpha = exp2f(m_run[f] - m_new);
-                m_run[f] = m_new;
-                float ps = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float p = exp2f(v[j] - m_new);
-                    ps += p;
-                    pf[f][j] = (bf16)p;
-                }
-                l_run[f] = l_run[f] * alpha + ps;
-#pragma unroll
-                for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
-            }
-            // ---- O^T += V^T . P^T ----
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
                 const char* vrow = v_lds + (d * 16 + fr) * VP + (sub * 32 + fg * 4) * 2;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                 const short8v packed = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, packed);
 #pragma unroll
-                for (int f = 0; f < QF; ++f) oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f], oacc[f][d], 0, 0, 0);
+                for (int f = 0; f < QF; ++f) oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f][sub], oacc[f][d], 0, 0, 0);
             }
         }
     }
@@ -183,15 +186,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
 }
 
-template <int DPAD>
+template <int DPAD, int DB>
 static int launch_dpad(const AttnArgs& a, hipStream_t st) {
     const int BH = a.B * a.H;
     ProfScope ps("flash_attention", 4.0 * BH * (double)a.nq * a.nk * a.hd,
                  2.0 * BH * (2.0 * a.nq * a.hd + 2.0 * a.nk * a.hd), st);
     if (a.nq >= 128) {
-        hipLaunchKernelGGL((attn_fwd_kernel<DPAD, 2>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 2>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((attn_fwd_kernel<DPAD, 1>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 1>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
     }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -200,14 +203,15 @@ static int launch_dpad(const AttnArgs& a, hipStream_t st) {
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     MRISR_REQUIRE(a.nkpad % 64 == 0 && a.nk >= 1 && a.nk <= a.nkpad, "attention: key padding");
     MRISR_REQUIRE(a.hd % 4 == 0 && a.hd <= a.dpad, "attention: head dim");
-    switch (a.dpad) {
-        case 32: return launch_dpad<32>(a, st);
-        case 64: return launch_dpad<64>(a, st);
-        case 96: return launch_dpad<96>(a, st);
-        case 128: return launch_dpad<128>(a, st);
-        case 160: return launch_dpad<160>(a, st);
-        default: MRISR_REQUIRE(false, "attention: unsupported padded head dim (32/64/96/128/160)");
-    }
+    const int db = (a.hd + 15) / 16;
+#define ATT_CASE(DP, DBV) if (a.dpad == DP && db == DBV) return launch_dpad<DP, DBV>(a, st);
+    ATT_CASE(32, 1) ATT_CASE(32, 2)
+    ATT_CASE(64, 3) ATT_CASE(64, 4)
+    ATT_CASE(96, 5) ATT_CASE(96, 6)
+    ATT_CASE(128, 7) ATT_CASE(128, 8)
+    ATT_CASE(160, 9) ATT_CASE(160, 10)
+#undef ATT_CASE
+    MRISR_REQUIRE(false, "attention: unsupported (padded head dim, head dim) combination");
     return 0;
 }
 

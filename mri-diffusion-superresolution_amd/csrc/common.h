@@ -97,6 +97,11 @@ struct GemmArgs {
     // profiler only: algorithmic work of this launch (0 -> derived from M, N, K)
     double alg_flops = 0.0, alg_bytes = 0.0;
     int tile = 0;  // kernel configuration chosen by gemm_choose (0: let launch_gemm plan)
+    // LoRA rank-r update applied in the epilogue: out[m][n] += sum_q z[m][zoff(n)+q] * lb[n][q],
+    //   z = x A^T (f32, from launch_lora_down), lb = (alpha/r) * B (f32); zoff(n) = (n / lora_secN) * lora_r
+    const float* lora_z = nullptr;
+    const float* lora_b = nullptr;
+    int lora_r = 0, lora_zld = 0, lora_secN = 1;
 };
 
 template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);
@@ -153,6 +158,9 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st);
 template <typename T>
 int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, float* y, int ldy, int rows, int N,
                      int K, int silu_in, hipStream_t st);
+// LoRA down-projection z[M][R] = x[M][K] . A[R][K]^T  (x, A of type T; z f32): one wave per row, memory-bound
+template <typename T>
+int launch_lora_down(const void* x, int ldx, const void* A, float* z, int M, int K, int R, hipStream_t st);
 // sinusoidal timestep embedding [rows][dim] = [cos | sin], t from device int64 (scalar broadcast or [rows])
 int launch_timestep_embedding(const long long* t, int t_is_scalar, float* out, int rows, int dim, hipStream_t st);
 // direct NHWC conv for tiny channel counts (conv_in, conv_out, ControlNet condition embedding)

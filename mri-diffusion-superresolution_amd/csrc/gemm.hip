@@ -84,6 +84,16 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
     if (g.bias) load4<float>(g.bias + n0, b4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = v[r] * alpha + b4[r];
+    if (g.lora_z) {
+        // fused LoRA: the rank-r update of these 4 columns (r is tiny: 4 FMAs per output for rank 4)
+        const float* zr = g.lora_z + (size_t)m * g.lora_zld + (n0 / g.lora_secN) * g.lora_r;
+        const float* lb = g.lora_b + (size_t)n0 * g.lora_r;
+        for (int q = 0; q < g.lora_r; ++q) {
+            const float zq = zr[q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += zq * lb[r * g.lora_r + q];
+        }
+    }
     if (g.rowvec) {
         float t4[4];
         load4<float>(g.rowvec + (size_t)(m / g.rowvec_div) * g.rowvec_ld + n0, t4);
@@ -848,6 +858,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     if (g.out_mode == OUT_HEADS) g.out_mode = OUT_ROWS;
     g.out = g_ts.p[3]; g.ldo = g.act == ACT_GEGLU ? g.N / 2 : g.N;
     if (g.resid) { g.resid = g_ts.p[3]; g.ldr = g.ldo; }
+    g.lora_z = nullptr;  // the rank-r epilogue term is negligible for ranking the candidates
     const int nkt = g.K / 64;
     const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     double best = 1e30;

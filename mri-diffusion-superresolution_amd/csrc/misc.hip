@@ -76,6 +76,118 @@ int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, 
     return 0;
 }
 
+// z[m][q] = sum_k x[m][k] * A[q][k]: one wave per row m, lanes stride over 16-byte chunks of k; A (R x K, a few KB)
+// stays in L1/L2.  Reads x exactly once: bandwidth-bound, ~5 us for 32768 x 320 bf16.
+template <typename T, int RMAX>
+__global__ __launch_bounds__(256) void lora_down_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ A,
+                                                        float* __restrict__ z, int M, int K, int R) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) acc[q] = 0.f;
+    for (int k = lane * VE; k < K; k += 64 * VE) {
+        float xv[VE];
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (size_t)m * ldx + k);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) xv[e] = (float)t[e];
+        } else {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + k);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) xv[e] = t[e];
+        }
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+            if (q < R) {
+                if constexpr (sizeof(T) == 2) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (size_t)q * K + k);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[q] += xv[e] * (float)a[e];
+                } else {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)q * K + k);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[q] += xv[e] * a[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+        if (q < R) {
+            const float s = wsum(acc[q]);
+            if (lane == 0) z[(size_t)m * R + q] = s;
+        }
+    }
+}
+// bf16 fast path: the same product on the matrix cores, no LDS and no cross-lane reduction.  A wave owns 16 rows:
+// per 32-deep k step it loads one x fragment (16 rows x 32 k) and NQ adapter fragments (16 q x 32 k) straight from
+// global/L1 into MFMA operand layout; D[row][q] accumulates in registers.
+template <int NQ>
+__global__ __launch_bounds__(256) void lora_down_mfma_kernel(const bf16* __restrict__ x, int ldx,
+                                                             const bf16* __restrict__ A, float* __restrict__ z, int M,
+                                                             int K, int R) {
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (m0 >= M) return;
+    const bf16* xr = x + (size_t)min(m0 + fr, M - 1) * ldx + fg * 8;
+    const bf16* ar[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) ar[b] = A + (size_t)min(b * 16 + fr, R - 1) * K + fg * 8;
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k += 32) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + k);
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ar[b] + k);
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, af, acc[b], 0, 0, 0);  // D[row = 4fg+r][q = fr]
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        const int q = b * 16 + fr;
+        if (q < R) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + fg * 4 + r;
+                if (m < M) z[(size_t)m * R + q] = acc[b][r];
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_lora_down(const void* x, int ldx, const void* A, float* z, int M, int K, int R, hipStream_t st) {
+    if (sizeof(T) == 2 && K % 32 == 0 && R <= 48) {
+        ProfScope ps("lora_down", 2.0 * M * (double)R * K, (double)M * K * 2.0, st);
+        const dim3 grid((M + 63) / 64);
+        const bf16* xp = reinterpret_cast<const bf16*>(x);
+        const bf16* ap = reinterpret_cast<const bf16*>(A);
+        if (R <= 16) hipLaunchKernelGGL((lora_down_mfma_kernel<1>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+        else if (R <= 32) hipLaunchKernelGGL((lora_down_mfma_kernel<2>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+        else hipLaunchKernelGGL((lora_down_mfma_kernel<3>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+        MRISR_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    MRISR_REQUIRE(K % (16 / (int)sizeof(T)) == 0 && R >= 1 && R <= 48, "lora_down: K alignment / rank");
+    ProfScope ps("lora_down", 2.0 * M * (double)R * K, (double)M * K * sizeof(T), st);
+    const dim3 grid((M + 3) / 4);
+    const T* xp = reinterpret_cast<const T*>(x);
+    const T* ap = reinterpret_cast<const T*>(A);
+    if (R <= 4) hipLaunchKernelGGL((lora_down_kernel<T, 4>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+    else if (R <= 8) hipLaunchKernelGGL((lora_down_kernel<T, 8>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+    else if (R <= 12) hipLaunchKernelGGL((lora_down_kernel<T, 12>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+    else if (R <= 24) hipLaunchKernelGGL((lora_down_kernel<T, 24>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+    else hipLaunchKernelGGL((lora_down_kernel<T, 48>), grid, dim3(256), 0, st, xp, ldx, ap, z, M, K, R);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void timestep_embedding_kernel(const long long* __restrict__ t, int t_is_scalar, float* __restrict__ out,
                                           int rows, int dim) {
     const int half = dim / 2;
@@ -130,8 +242,82 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectConvArgs a
         y[i] = from_f32<T>(acc);
     }
 }
+// Small-fan-in convolution (conv_in: 3x3x4 = 36 taps): the transposed filter bank [tap*Cin][Cout] sits in LDS, a
+// thread produces 8 consecutive output channels of one pixel, so x is read once per pixel-thread-group (broadcast
+// within the wave), filters come as 16-byte LDS vectors and the store is one 16/32-byte vector per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void small_conv_kernel(const DirectConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    T* wT = reinterpret_cast<T*>(sm_raw);
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* w = reinterpret_cast<const T*>(a.w);
+    T* y = reinterpret_cast<T*>(a.y);
+    const int Kt = a.ks * a.ks * a.Cin;
+    for (int i = threadIdx.x; i < Kt * a.Cout; i += 256) {
+        const int k = i / a.Cout, n = i - k * a.Cout;
+        wT[i] = w[(size_t)n * Kt + k];
+    }
+    __syncthreads();
+    const int CG = a.Cout / 8;
+    const long long items = (long long)a.B * a.Hout * a.Wout * CG;
+    for (long long it = blockIdx.x * 256ll + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int cg = (int)(it % CG);
+        const long long m = it / CG;
+        const int ox = (int)(m % a.Wout);
+        const int oy = (int)((m / a.Wout) % a.Hout);
+        const int b = (int)(m / ((long long)a.Wout * a.Hout));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = a.bias ? a.bias[cg * 8 + e] : 0.f;
+        for (int ky = 0; ky < a.ks; ++ky) {
+            const int iy = oy * a.stride + ky - a.pad;
+            if (iy < 0 || iy >= a.Hin) continue;
+            for (int kx = 0; kx < a.ks; ++kx) {
+                const int ix = ox * a.stride + kx - a.pad;
+                if (ix < 0 || ix >= a.Win) continue;
+                const T* xp = x + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin;
+                const T* wr = wT + (size_t)((ky * a.ks + kx) * a.Cin) * a.Cout + cg * 8;
+                for (int c = 0; c < a.Cin; ++c) {
+                    const float xv = to_f32(xp[c]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += xv * to_f32(wr[(size_t)c * a.Cout + e]);
+                }
+            }
+        }
+        const size_t o = (size_t)m * a.Cout + cg * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[e];
+            if (a.act == ACT_SILU) v = silu_f(v);
+            else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+            if (a.add) v += to_f32(reinterpret_cast<const T*>(a.add)[o + e]);
+            acc[e] = v;
+        }
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (bf16)acc[e];
+            *reinterpret_cast<bf16x8*>(y + o) = ov;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[o + e] = acc[e];
+        }
+    }
+}
+
 template <typename T>
 int launch_direct_conv(const DirectConvArgs& a, hipStream_t st) {
+    const size_t wbytes = (size_t)a.ks * a.ks * a.Cin * a.Cout * sizeof(T);
+    if (a.Cout % 8 == 0 && wbytes <= 48 * 1024) {
+        const long long items = (long long)a.B * a.Hout * a.Wout * (a.Cout / 8);
+        long long blocks = (items + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        ProfScope ps("small_conv", 2.0 * items * 8 * a.ks * a.ks * a.Cin,
+                     sizeof(T) * ((double)a.B * a.Hin * a.Win * a.Cin + (double)items * 8), st);
+        hipLaunchKernelGGL(small_conv_kernel<T>, dim3((unsigned)blocks), dim3(256), wbytes, st, a);
+        MRISR_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const long long total = (long long)a.B * a.Hout * a.Wout * a.Cout;
     long long blocks = (total + 255) / 256;
     if (blocks > 65535 * 4) blocks = 65535 * 4;
@@ -383,6 +569,7 @@ int launch_resshift_forward(const float* hr, const float* lr, const float* noise
     template int launch_gemv_rows<T>(const float*, int, const void*, const float*, float*, int, int, int, int, int, \
                                      hipStream_t);                                                                 \
     template int launch_direct_conv<T>(const DirectConvArgs&, hipStream_t);                                        \
+    template int launch_lora_down<T>(const void*, int, const void*, float*, int, int, int, hipStream_t);           \
     template int launch_nchw_to_nhwc<T>(const void*, int, void*, int, int, int, int, hipStream_t);                 \
     template int launch_nhwc_to_nchw<T>(const void*, void*, int, int, int, int, int, float, hipStream_t);          \
     template int launch_add_inplace<T>(void*, const void*, long long, hipStream_t);                                \

@@ -105,27 +105,32 @@ struct Packer {
         const bool fused_lora = m.cfg.lora_rank > 0 && m.cfg.lora_fused;
         int ntot = 0, k = 0;
         bool any_lora = false;
-        int rsum = 0;
+        int rsum = 0, rmod = 0, nmod0 = 0;
         for (auto& mod : mods) {
             const RawParam* w = need(mod + ".weight");
             if (!w) return l;
             ntot += (int)w->shape[0];
             k = (int)w->shape[1];
             const RawParam* la = m.find(mod + ".lora_A.default.weight");
-            if (la) { any_lora = true; rsum += (int)la->shape[0]; }
+            if (la) { any_lora = true; rsum += (int)la->shape[0]; rmod = (int)la->shape[0]; }
+            if (!nmod0) nmod0 = (int)w->shape[0];
         }
-        constexpr int BK = 128 / (int)sizeof(T);
         l.n = ntot;
         l.k = k;
-        l.rpad = (any_lora && fused_lora) ? round_up(rsum, BK) : 0;
-        l.r = l.rpad ? rsum : 0;
-        const int ktot = k + l.rpad;
-        l.w = m.new_packed((size_t)ntot * ktot * sizeof(T), l.rpad > 0);
-        if (!l.w) { err = 4; return l; }
-        if (l.rpad) {
-            l.loraA = m.new_packed((size_t)l.rpad * k * sizeof(T), true);
-            if (!l.loraA) { err = 4; return l; }
+        const int ktot = k;
+        float* lbuf = nullptr;
+        if (any_lora && fused_lora) {
+            // one rank-r adapter slot per fused module (modules without an adapter keep zero A rows / B rows)
+            l.r = rmod;
+            l.R = (int)mods.size() * rmod;
+            l.secN = nmod0;
+            l.loraA = m.new_packed((size_t)l.R * k * sizeof(T), true);
+            lbuf = static_cast<float*>(m.new_packed((size_t)ntot * rmod * sizeof(float), true));
+            if (!l.loraA || !lbuf) { err = 4; return l; }
+            l.loraB = lbuf;
         }
+        l.w = m.new_packed((size_t)ntot * ktot * sizeof(T), false);
+        if (!l.w) { err = 4; return l; }
         bool has_bias = false;
         for (auto& mod : mods) has_bias |= m.find(mod + ".bias") != nullptr;
         float* bias = nullptr;
@@ -153,12 +158,12 @@ struct Packer {
             if (launch_pack_rows<T>(wsrc, n, k, l.w, ktot, row, 0, geglu ? 1 : 0, n / 2, 1.0f, st)) err = 5;
             if (la && lb && fused_lora) {
                 const int r = (int)la->shape[0];
-                // A rows -> loraA[rcol .. rcol+r), s*B -> tail columns k+rcol.. of this module's rows
+                if (r != l.r || n != l.secN) { set_error("fused LoRA needs the same rank / width for every fused module: " + mod); err = 6; }
+                // A rows -> loraA[rcol .. rcol+r);  (alpha/r) * B -> f32 [n][r] rows of this module
                 if (launch_pack_rows<T>(static_cast<const float*>(la->data->p), r, k, l.loraA, k, rcol, 0, 0, 0, 1.0f, st)) err = 5;
-                if (launch_pack_rows<T>(static_cast<const float*>(lb->data->p), n, r, l.w, ktot, row, k + rcol, 0, 0,
-                                        m.lora_scale, st)) err = 5;
-                rcol += r;
+                if (launch_pack_rows<float>(static_cast<const float*>(lb->data->p), n, r, lbuf, r, row, 0, 0, 0, m.lora_scale, st)) err = 5;
             }
+            if (fused_lora && any_lora) rcol += l.r;
             if (const RawParam* b = m.find(mod + ".bias")) {
                 const float* bsrc = static_cast<const float*>(b->data->p);
                 if (geglu) {
@@ -422,18 +427,15 @@ struct Runner {
         GemmArgs g = custom ? *custom : GemmArgs();
         const size_t mk = m.arena.mark();
         g.a0 = x; g.c0 = lw.k; g.lda0 = lda;
-        if (lw.rpad) {
-            // LoRA down-projection z = x A^T  ([M][rpad]); the up-projection s*B rides in W's K tail
-            void* z = alloc((size_t)M * lw.rpad * sizeof(T));
+        if (lw.R) {
+            // LoRA: z = x A^T (f32 [M][R], one bandwidth-bound pass over x); the rank-r up-projection (alpha/r) B z is
+            // accumulated in the projection GEMM's epilogue
+            float* z = static_cast<float*>(alloc((size_t)M * lw.R * sizeof(float)));
             if (!z) return 7;
-            GemmArgs d;
-            d.a0 = x; d.c0 = lw.k; d.lda0 = lda; d.w = lw.loraA; d.M = M; d.N = lw.rpad; d.K = lw.k;
-            d.out = z; d.ldo = lw.rpad;
-            d.alg_flops = 2.0 * M * (double)lw.r * lw.k;
-            TRY(run_gemm(d));
-            g.a1 = z; g.c1 = lw.rpad; g.lda1 = lw.rpad;
+            if (!dry) TRY(launch_lora_down<T>(x, lda, lw.loraA, z, M, lw.k, lw.R, st));
+            g.lora_z = z; g.lora_zld = lw.R; g.lora_b = lw.loraB; g.lora_r = lw.r; g.lora_secN = lw.secN;
         }
-        g.w = lw.w; g.M = M; g.N = lw.n; g.K = lw.k + lw.rpad;
+        g.w = lw.w; g.M = M; g.N = lw.n; g.K = lw.k;
         g.alg_flops = 2.0 * M * (double)lw.n * (lw.k + lw.r);
         g.bias = lw.b; g.act = act; g.resid = resid; g.ldr = ldr;
         if (g.out_mode != OUT_HEADS) { g.out = out; g.ldo = ldo; }
@@ -464,7 +466,7 @@ struct Runner {
             if (x1) { g.a1 = x1->p; g.c1 = x1->C; g.lda1 = x1->C; }
             g.a0 = x.p; g.c0 = x.C; g.lda0 = x.C;
             g.w = r.sc.w; g.M = (int)x.rows(); g.N = r.cout; g.K = r.cin; g.bias = r.sc.b; g.out = o.p; g.ldo = r.cout;
-            MRISR_REQUIRE(r.sc.rpad == 0, "shortcut has no LoRA");
+            MRISR_REQUIRE(r.sc.R == 0, "shortcut has no LoRA");
             TRY(run_gemm(g));
             res = o;
         } else {

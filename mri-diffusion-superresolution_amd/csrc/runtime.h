@@ -71,11 +71,15 @@ struct ConvW {  // packed [cout][ks*ks*cin] in compute dtype, bias f32
     const float* b = nullptr;
     int cin = 0, cout = 0, ks = 3;
 };
-struct LinW {  // packed [n][ktot] in compute dtype (ktot = k + rpad), bias f32 (GEGLU: interleaved)
+struct LinW {  // packed [n][k] in compute dtype, bias f32 (GEGLU: interleaved)
     void* w = nullptr;
     const float* b = nullptr;
-    int n = 0, k = 0, rpad = 0, r = 0;  // r: sum of the LoRA ranks riding in the K tail (rpad = r rounded to a K tile)
-    void* loraA = nullptr;  // [rpad][k] compute dtype (rows >= used rank are zero) or null
+    int n = 0, k = 0;
+    // fused LoRA (peft): per fused module one rank-r adapter.  loraA [R = nmod*r][k] compute dtype, loraB f32 [n][r]
+    // already scaled by lora_alpha/r; output column n uses z columns (n / secN) * r .. +r
+    int r = 0, R = 0, secN = 1;
+    void* loraA = nullptr;
+    const float* loraB = nullptr;
 };
 
 struct Act {  // NHWC activation (or token rows when H*W is the token count)

@@ -38,7 +38,7 @@ SHAPES = [
     ("lin 1280->1280 (+lora) M2k", 0, B * 64, 1280, 1344, None, 64),
     ("shortcut 1920->640 M8k", 0, B * 256, 640, 1920, None, 640),
 ]
-TILES = {14: "bl128x128", 16: "bl128x64", 19: "bl128x128d4", 20: "bl128x64d4", 22: "bl64x64d4", 23: "bl128x128d3"}
+TILES = {14: "bl128x128", 15: "bl256x64", 16: "bl128x64", 17: "bl64x64", 18: "bl64x128"}
 
 
 def run(shape, tile, splitk, iters=20):

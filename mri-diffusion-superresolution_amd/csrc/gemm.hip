@@ -395,6 +395,10 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 // (small M / deep K), where the 2-stage loop is bound by one exposed load latency per K tile.
 template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
+    // Only the 2-stage form is instantiated: it synchronises with vmcnt(0), which is correct however out-of-range
+    // (zero-fill) LDS-DMA instructions retire.  The counted-vmcnt ring below is kept for reference but must not be used
+    // with out-of-range offsets (fully out-of-range instructions retire out of order; see gemm_big_kernel).
+    static_assert(NSTAGE == 2, "ring form disabled: unsafe with out-of-range LDS-DMA");
     typedef bf16 T;
     constexpr int BK = 64;
     constexpr int A_IT = BM / 32, W_IT = BN / 32;
@@ -730,13 +734,7 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     X(15, 256, 64, 4, 1, 2)    \
     X(16, 128, 64, 2, 2, 2)    \
     X(17, 64, 64, 2, 2, 2)     \
-    X(18, 64, 128, 2, 2, 2)    \
-    X(19, 128, 128, 2, 2, 4)   \
-    X(20, 128, 64, 2, 2, 4)    \
-    X(21, 64, 128, 2, 2, 4)    \
-    X(22, 64, 64, 2, 2, 4)     \
-    X(23, 128, 128, 2, 2, 3)   \
-    X(24, 256, 64, 4, 1, 3)
+    X(18, 64, 128, 2, 2, 2)
 static int prepare_bls() {
 #define X(id, bm, bn, wm, wn, ns) if (prepare_bl<bm, bn, wm, wn, ns>()) return 1;
     BL_CFGS(X)
@@ -872,9 +870,9 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventCreate(&t0));
     MRISR_CHECK_HIP(hipEventCreate(&t1));
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
-    static const int cand[] = {14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
+    static const int cand[] = {14, 15, 16, 17, 18};
     for (int tile : cand) {
-        const bool deep = tile >= 19;
+        const bool deep = false;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
         for (int s = 1; s <= 32; s *= 2) {
             if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096)) break;

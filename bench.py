@@ -170,10 +170,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f} s for {args.steps} batches")
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from mrisr import dist as mdist
+    elapsed = mdist.max_over_ranks(elapsed, dev)  # slowest rank's wall time
     finite = bool(torch.isfinite(lat).all())
 
     if rank != 0:

@@ -771,7 +771,8 @@ struct Runner {
         Act xn, y;
         TRY(gn(x, nullptr, m.norm_out, true, m.cfg.norm_eps, &xn));
         // conv_out (Cout = 4): through the implicit GEMM (rows beyond N read zeros), 20x faster than the direct kernel
-        TRY(conv3(xn, nullptr, m.conv_out, 1, 0, nullptr, 0, 1, nullptr, ACT_NONE, &y));
+        if (m.conv_out.cout % 4 == 0) TRY(conv3(xn, nullptr, m.conv_out, 1, 0, nullptr, 0, 1, nullptr, ACT_NONE, &y));
+        else TRY(direct(xn, m.conv_out, 1, ACT_NONE, nullptr, &y));  // e.g. the 1-channel MNIST-plumbing config
         return export_act(y, out, 1.0f);
     }
 

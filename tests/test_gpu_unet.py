@@ -226,3 +226,30 @@ def test_sampler_trajectory_states_and_graph_equals_eager(tiny, golden_dir):
         torch.cuda.synchronize()
         ref = torch.from_numpy(g["states"][k])
         assert rel(lat, ref) < 1e-3 and maxrel(lat, ref) < 1e-3, (k, rel(lat, ref))
+
+
+def test_config1_mnist_plumbing_ddim10(golden_dir):
+    """BASELINE config 1 ("MNIST_Super_Resolution.ipynb path"): 1-channel 2-level UNet, 28x28 padded to 32x32, bs=8,
+    10 steps, linear betas 1e-4..0.02 (nb MNIST c5:1-9).  HIP sampler (f32) vs the CPU oracle loop."""
+    import mrisr
+    from oracle import sampler as osa
+    from oracle import schedulers as osch
+    from oracle import unet as ou
+    cfg = ou.MNIST
+    p = ou.init_unet_params(cfg, seed=55, perturb_norm=True)
+    g = torch.Generator().manual_seed(56)
+    digits = torch.randn((8, 1, 28, 28), generator=g)
+    x = torch.nn.functional.pad(digits, (2, 2, 2, 2))  # 28 -> 32 (divisible by 2^(levels-1))
+    ctx = torch.randn((8, 77, cfg.cross_attention_dim), generator=g)
+    so = osch.OracleScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear")
+    so.set_timesteps(10)
+    traj = osa.ddim_sample(ou.OracleUNet(p, cfg), x, ctx, so)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32")
+    net.load_state_dict(p)
+    sp = mrisr.DDIMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear")
+    sp.set_timesteps(10)
+    lat = x.cuda().clone().contiguous()
+    mrisr.Sampler(net, sp, kind="ddim").run(lat, ctx.cuda())
+    torch.cuda.synchronize()
+    assert rel(lat, traj[-1]) < 1e-3 and maxrel(lat, traj[-1]) < 1e-3
+    assert lat[:, :, 2:30, 2:30].shape == (8, 1, 28, 28)

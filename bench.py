@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lora-merged", action="store_true", help="merge LoRA into W instead of the fused rank tail")
+    ap.add_argument("--ddim-steps", type=int, default=N_DDIM, help="(profiling only) fewer denoising steps; the metric needs 50")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
+                    help="per-kernel-class HBM bytes per launch from tools/collect_traffic.sh (PMC passes of this command)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,7 +141,7 @@ def main():
     torch.cuda.synchronize()
     log("weights packed")
     sched = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
-    sched.set_timesteps(N_DDIM)
+    sched.set_timesteps(args.ddim_steps)
     sampler = mrisr.Sampler(unet, sched, kind="ddim")
     B = args.batch
     lr_lat, ctx, noise = synthetic_batch(B, dev, rank)
@@ -212,18 +215,25 @@ def main():
                 "all_gemm": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "share_of_step_time": all_ms / total_ms,
                              "alg_gflop_per_unet_step": all_fl / 2 / 1e9},
                 "classes_ms_per_step": {k: round(v["ms"] / 2, 4) for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["ms"])}}
+        try:  # HBM bytes per launch of the dominant kernel, from the committed PMC collection of this same command
+            tj = json.load(open(args.traffic_json))
+            if dom_name in tj:
+                roof["traffic"] = tj[dom_name]["hbm_bytes_per_launch"]
+                roof["alg_bytes_per_launch"] = d["bytes"] / d["launches"]
+        except (OSError, ValueError):
+            pass
 
     total_slices = world * B * args.steps
     value = total_slices / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    step_ms = ms_per_step / N_DDIM
+    step_ms = ms_per_step / args.ddim_steps
     out = {
         "metric": "MRI slices/sec (50-step DDIM, 256^2, bs=32)", "value": value, "unit": "slices/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[1]: 256x256 1-ch synthetic MRI slices -> 4x32x32 latents, SD-1.5-size UNet "
                                "(859.5M params, random init) + rank-4 LoRA, 50-step DDIM, bs=32 per GPU",
-                   "slices_per_gpu_per_step": B, "ddim_steps": N_DDIM, "parallelism": f"slice-sharded x{world} (no collective)",
+                   "slices_per_gpu_per_step": B, "ddim_steps": args.ddim_steps, "parallelism": f"slice-sharded x{world} (no collective)",
                    "lora": "merged" if args.lora_merged else "fused rank tail", "hipgraph": not args.no_graph},
         "denoise_step_ms": step_ms,
         "unet_tflops_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms,

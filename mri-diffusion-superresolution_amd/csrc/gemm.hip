@@ -15,6 +15,7 @@
 #include "common.h"
 #include "prof.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 
@@ -836,6 +837,19 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     char key[200];
     snprintf(key, sizeof(key), "%d,%d,%d,c%d,s%d,u%d,%d,%d,a%d,o%d,b%d,r%d,v%d,h%d,w%d", g0.M, g0.N, g0.K, g0.conv, g0.stride, g0.ups, g0.c0,
              g0.c1, g0.act, g0.out_mode, g0.batch, g0.resid ? 1 : 0, g0.rowvec ? 1 : 0, g0.Hin, g0.Win);
+    static bool cache_loaded = false;
+    const char* cache_path = getenv("MRISR_TUNE_CACHE");  // optional on-disk table: "key<TAB>tile<TAB>split" per line
+    if (!cache_loaded) {
+        cache_loaded = true;
+        if (cache_path) {
+            if (FILE* f = fopen(cache_path, "r")) {
+                char k[256];
+                int t, sp;
+                while (fscanf(f, "%255[^\t]\t%d\t%d\n", k, &t, &sp) == 3) g_tuned[k] = {t, sp};
+                fclose(f);
+            }
+        }
+    }
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) { *tile_out = it->second.first; *split_out = it->second.second; return 0; }
     // scratch operands
@@ -902,6 +916,12 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     mrisr_prof_enable_internal(prof_was ? 1 : 0);
     g_tuned[key] = {bt, bs};
+    if (cache_path) {
+        if (FILE* f = fopen(cache_path, "a")) {
+            fprintf(f, "%s\t%d\t%d\n", key, bt, bs);
+            fclose(f);
+        }
+    }
     *tile_out = bt;
     *split_out = bs;
     return 0;

@@ -89,10 +89,21 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
         // fused LoRA: the rank-r update of these 4 columns (r is tiny: 4 FMAs per output for rank 4)
         const float* zr = g.lora_z + (size_t)m * g.lora_zld + (n0 / g.lora_secN) * g.lora_r;
         const float* lb = g.lora_b + (size_t)n0 * g.lora_r;
-        for (int q = 0; q < g.lora_r; ++q) {
-            const float zq = zr[q];
+        if (g.lora_r == 4) {  // the common rank: five 16-byte loads instead of twenty scalar ones
+            float z4[4];
+            load4<float>(zr, z4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += zq * lb[r * g.lora_r + q];
+            for (int r = 0; r < 4; ++r) {
+                float l4[4];
+                load4<float>(lb + r * 4, l4);
+                v[r] += z4[0] * l4[0] + z4[1] * l4[1] + z4[2] * l4[2] + z4[3] * l4[3];
+            }
+        } else {
+            for (int q = 0; q < g.lora_r; ++q) {
+                const float zq = zr[q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += zq * lb[r * g.lora_r + q];
+            }
         }
     }
     if (g.rowvec) {
@@ -131,6 +142,30 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
         const size_t bh = (size_t)b * g.nheads + h;
         if (!tr) {
             store4<T>(base + (bh * g.npad + tok) * g.dpad + dd, v);
+        } else if (sizeof(T) == 2 && (g.ntok & 3) == 0 && (g.M & 3) == 0) {
+            // V^T [b][h][d][token]: the lane holds 4 d-values of ONE token, so a direct store is 4 x 2 bytes at a
+            // token stride.  Exchange with the 3 neighbouring token lanes (fr ^ 1, fr ^ 2) so that every lane ends up
+            // with 4 consecutive tokens of ONE d row: a single 8-byte store (all lanes of the exchange are valid
+            // together: tile rows and M are multiples of 4).
+            const int fr = threadIdx.x & 15;
+            const bool odd = fr & 1;
+            const float s0 = __shfl_xor(odd ? v[0] : v[2], 1);
+            const float s1 = __shfl_xor(odd ? v[1] : v[3], 1);
+            // even lane: rows d0,d1 for tokens (t, t+1); odd lane: rows d2,d3 for tokens (t-1, t)
+            const float a0 = odd ? s0 : v[0], a1 = odd ? v[2] : s0;   // row A: (token lo, token hi)
+            const float c0 = odd ? s1 : v[1], c1 = odd ? v[3] : s1;   // row C
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            const bf16x2 pa = {(bf16)a0, (bf16)a1}, pc = {(bf16)c0, (bf16)c1};
+            const unsigned ua = __builtin_bit_cast(unsigned, pa), uc = __builtin_bit_cast(unsigned, pc);
+            const bool hi2 = fr & 2;
+            // lanes (fr&2)==0 keep row A and hand row C to fr^2; lanes (fr&2)!=0 keep row C and hand row A over
+            const unsigned recv = __shfl_xor(hi2 ? ua : uc, 2);
+            const unsigned w0 = hi2 ? recv : ua, w1 = hi2 ? uc : recv;  // tokens (4k,4k+1) then (4k+2,4k+3)
+            // which d row this lane now owns: even/odd picks (d0|d1) vs (d2|d3); hi2 picks the second of the pair
+            const int drow = (odd ? 2 : 0) + (hi2 ? 1 : 0);
+            const int tok4 = tok & ~3;
+            T* o = base + (bh * g.dpad + dd + drow) * g.npad + tok4;
+            *reinterpret_cast<uint2*>(o) = make_uint2(w0, w1);
         } else {
             T* o = base + (bh * g.dpad + dd) * g.npad + tok;
 #pragma unroll
@@ -600,18 +635,20 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
         return;
     }
     if (g.act == ACT_GEGLU) {
+        if constexpr (NF % 2 == 0) {
 #pragma unroll
-        for (int i = 0; i < NF; i += 2)
+            for (int i = 0; i < NF; i += 2)
 #pragma unroll
-            for (int j = 0; j < MF; ++j) {
-                const int m = m0 + wm0 + j * 16 + fr;
-                const int n = n0 + wn0 + i * 16 + fg * 4;
-                if (m < g.M && n < g.N) {
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    float vg[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
-                    epilogue4<T>(g, z, m, n, v, vg);
+                for (int j = 0; j < MF; ++j) {
+                    const int m = m0 + wm0 + j * 16 + fr;
+                    const int n = n0 + wn0 + i * 16 + fg * 4;
+                    if (m < g.M && n < g.N) {
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        float vg[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
+                        epilogue4<T>(g, z, m, n, v, vg);
+                    }
                 }
-            }
+        }
         return;
     }
 #pragma unroll
@@ -735,7 +772,15 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     X(15, 256, 64, 4, 1, 2)    \
     X(16, 128, 64, 2, 2, 2)    \
     X(17, 64, 64, 2, 2, 2)     \
-    X(18, 64, 128, 2, 2, 2)
+    X(18, 64, 128, 2, 2, 2)    \
+    X(25, 128, 160, 2, 2, 2)   \
+    X(26, 64, 160, 2, 2, 2)    \
+    X(27, 160, 160, 2, 2, 2)   \
+    X(28, 128, 192, 2, 2, 2)   \
+    X(29, 192, 128, 2, 2, 2)   \
+    X(30, 160, 128, 2, 2, 2)   \
+    X(31, 96, 160, 2, 2, 2)
+
 static int prepare_bls() {
 #define X(id, bm, bn, wm, wn, ns) if (prepare_bl<bm, bn, wm, wn, ns>()) return 1;
     BL_CFGS(X)
@@ -884,9 +929,11 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventCreate(&t0));
     MRISR_CHECK_HIP(hipEventCreate(&t1));
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
-    static const int cand[] = {14, 15, 16, 17, 18};
+    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
+        // 5 fragments per wave along N (BN = 160): no (u, gate) pairing for the GEGLU epilogue
+        if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
         for (int s = 1; s <= 32; s *= 2) {
             if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096)) break;

@@ -137,7 +137,7 @@ def test_attention_flash_online_softmax_rescale_branch():
     assert rel(y, ref) < 2e-2
 
 
-@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 25, 26, 27, 28, 29, 30, 31])
 @pytest.mark.parametrize("M,N,K,splitk", [(512, 320, 256, 1), (1000, 640, 384, 1), (256, 1280, 2048, 4), (300, 68, 192, 1),
                                           (4096, 960, 384, 1), (130, 320, 64, 1)])
 def test_linear_buffer_addressed_kernel(tile, M, N, K, splitk):
@@ -150,7 +150,7 @@ def test_linear_buffer_addressed_kernel(tile, M, N, K, splitk):
     assert rel(y, ref) < TOL["bf16"]
 
 
-@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 25, 26, 27, 28, 29, 30, 31])
 @pytest.mark.parametrize("B,Cin,Cout,H,stride,ups,splitk", [(2, 64, 320, 16, 1, False, 1), (1, 320, 320, 32, 1, False, 1),
                                                             (2, 128, 64, 8, 1, True, 1), (2, 64, 128, 16, 2, False, 1),
                                                             (3, 256, 256, 4, 1, False, 4), (1, 64, 64, 5, 1, False, 1)])
@@ -164,7 +164,7 @@ def test_conv3x3_buffer_addressed_kernel(tile, B, Cin, Cout, H, stride, ups, spl
     assert rel(y, ref) < TOL["bf16"]
 
 
-@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 28, 29, 30])
 def test_buffer_addressed_kernel_concat_and_geglu(tile):
     from mrisr import _lib as L
     from mrisr import ops

@@ -38,7 +38,7 @@ SHAPES = [
     ("lin 1280->1280 (+lora) M2k", 0, B * 64, 1280, 1344, None, 64),
     ("shortcut 1920->640 M8k", 0, B * 256, 640, 1920, None, 640),
 ]
-TILES = {14: "bl128x128", 15: "bl256x64", 16: "bl128x64", 17: "bl64x64", 18: "bl64x128"}
+TILES = {14: "bl128x128", 25: "bl128x160", 27: "bl160x160", 28: "bl128x192", 29: "bl192x128", 30: "bl160x128", 31: "bl96x160"}
 
 
 def run(shape, tile, splitk, iters=20):

@@ -783,6 +783,7 @@ extern "C" int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int
         MRISR_REQUIRE(M == B * g.Hout * g.Wout, "bench conv M");
     }
     g.w = wb.p; g.M = M; g.N = N; g.K = K; g.bias = (const float*)bias.p; g.out = ob.p; g.ldo = N;
+    if (const char* e = getenv("MRISR_BENCH_NOSTORE")) { if (e[0] == '1') g.out_mode = OUT_NONE; }  // experiment: epilogue without the store
     g.splitk = splitk;
     if (splitk <= 0) { g.splitk = 1; mrisr_debug_force_tile(tile); TRY(gemm_choose(g, true)); }
     if (g.splitk > 1) {

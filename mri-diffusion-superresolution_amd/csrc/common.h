@@ -58,7 +58,7 @@ void set_error(const std::string& msg);
 //   up-sampled, stride 1/2, zero padded).  Both operands are K-contiguous.
 // ---------------------------------------------------------------------------------------------
 enum GemmAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GEGLU = 3 };
-enum GemmOut : int { OUT_ROWS = 0, OUT_HEADS = 1, OUT_F32 = 2 };
+enum GemmOut : int { OUT_ROWS = 0, OUT_HEADS = 1, OUT_F32 = 2, OUT_NONE = 3 /* micro-benchmark only: epilogue math, no store */ };
 
 struct GemmArgs {
     // ---- A operand ----

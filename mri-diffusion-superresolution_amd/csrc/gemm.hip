@@ -126,7 +126,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += r4[r];
     }
-    if (g.out_mode == OUT_ROWS) {
+    if (g.out_mode == OUT_NONE) {
+        if (v[0] == 1.2345e30f) store4<T>(reinterpret_cast<T*>(g.out), v);  // benchmark-only: keep the math, drop the store
+    } else if (g.out_mode == OUT_ROWS) {
         store4<T>(reinterpret_cast<T*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
     } else if (g.out_mode == OUT_F32) {
         store4<float>(reinterpret_cast<float*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);

@@ -69,7 +69,7 @@ struct Packer {
 
     const RawParam* need(const std::string& k) {
         const RawParam* r = m.find(k);
-        if (!r) {
+        if (!r && !err) {  // keep the FIRST missing key as the message
             set_error("missing parameter: " + k);
             err = 3;
         }
@@ -295,6 +295,7 @@ static int finalize_t(Model& m, hipStream_t st) {
         for (int k = 0; k < m.num_skips(); ++k) m.cn_down.push_back(pk.linear({"controlnet_down_blocks." + std::to_string(k)}));
         m.cn_mid = pk.linear({"controlnet_mid_block"});
     }
+    if (pk.err) return pk.err;  // e.g. "missing parameter: <key>" (message already set)
     // all time_emb_proj linears as ONE [sum C][temb] matrix: a single weight-streaming launch per step
     {
         const int temb = 4 * c.block_out_channels[0];

@@ -1,0 +1,624 @@
+// Backward-pass kernels of the LoRA fine-tuning step: everything that is not a GEMM.
+// The dense contractions of the backward (conv / linear dgrad, attention products) reuse gemm.hip with transposed or
+// flipped weight copies packed at finalize; base weights are frozen, so only dX and the LoRA wgrads are produced.
+#include "common.h"
+#include "prof.h"
+
+namespace mrisr {
+
+template <typename T> struct BVec;
+template <> struct BVec<bf16> { static constexpr int N = 8; typedef bf16x8 type; };
+template <> struct BVec<float> { static constexpr int N = 4; typedef f32x4 type; };
+
+__device__ __forceinline__ float bw_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float silu_grad(float x) {  // d/dx [x * sigmoid(x)]
+    const float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_grad(float x) {  // d/dx [0.5 x (1 + erf(x / sqrt2))]
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+static inline unsigned bw_blocks(long long total) {
+    long long b = (total + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) backward.  y = act(xhat * gamma + beta), xhat = (x - mean) * rstd per (sample, group).
+//   ds = dy * act'(pre);  dxhat = ds * gamma;
+//   dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat))
+// Stage 1 accumulates S1 = sum dxhat, S2 = sum dxhat*xhat per (b, split, group) (same geometry as the forward stats);
+// stage 2 applies.  mean/rstd are re-derived from the forward's saved partial sums (fwd_partial).
+// The (concatenated) gradient is written to two destinations (dx0: first c0 channels, dx1: the rest), optionally
+// accumulating into them.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const GroupNormBwdArgs a, int slots, int RL) {
+    constexpr int VE = BVec<T>::N;
+    typedef typename BVec<T>::type vec_t;
+    extern __shared__ float sm[];  // [2][RL][C]
+    __shared__ float mean_s[64], rstd_s[64];
+    const int C = a.c0 + a.c1;
+    const int Cg = C / a.groups;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < a.groups) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < a.nsplit; ++q) {
+            const float* p = a.fwd_partial + (((size_t)b * a.nsplit + q) * a.groups + tid) * 2;
+            s1 += (double)p[0];
+            s2 += (double)p[1];
+        }
+        const double n = (double)a.HW * Cg;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    const int slot = tid % slots, rl = tid / slots;
+    const int rows_per = (a.HW + a.nsplit - 1) / a.nsplit;
+    const int r_beg = sp * rows_per, r_end = min(a.HW, r_beg + rows_per);
+    float s1[VPT][VE], s2[VPT][VE];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s1[v][e] = s2[v][e] = 0.f;
+    if (rl < RL) {
+        for (int r = r_beg + rl; r < r_end; r += RL) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int ch = (slot * VPT + v) * VE;
+                const T* src = ch < a.c0 ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                                         : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+                const vec_t x = *reinterpret_cast<const vec_t*>(src);
+                const vec_t dy = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(a.dy) + ((size_t)b * a.HW + r) * C + ch);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const int c = ch + e;
+                    const int gq = c / Cg;
+                    const float xh = ((float)x[e] - mean_s[gq]) * rstd_s[gq];
+                    float d = (float)dy[e];
+                    if (a.silu) d *= silu_grad(xh * a.gamma[c] + a.beta[c]);
+                    const float dxh = d * a.gamma[c];
+                    s1[v][e] += dxh;
+                    s2[v][e] += dxh * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int ch = (slot * VPT + v) * VE + e;
+                sm[(size_t)rl * C + ch] = s1[v][e];
+                sm[(size_t)(RL + rl) * C + ch] = s2[v][e];
+            }
+    }
+    __syncthreads();
+    if (tid < 2 * a.groups) {
+        const int gq = tid % a.groups, which = tid / a.groups;
+        double acc = 0.0;
+        for (int r = 0; r < RL; ++r) {
+            const float* row = sm + (size_t)(which * RL + r) * C + gq * Cg;
+            float t = 0.f;
+            for (int c = 0; c < Cg; ++c) t += row[c];
+            acc += (double)t;
+        }
+        a.bwd_partial[(((size_t)b * a.nsplit + sp) * a.groups + gq) * 2 + which] = (float)acc;
+    }
+}
+
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GroupNormBwdArgs a, int slots, int RL, int rows_per_block) {
+    constexpr int VE = BVec<T>::N;
+    typedef typename BVec<T>::type vec_t;
+    __shared__ float mean_s[64], rstd_s[64], m1_s[64], m2_s[64];
+    const int C = a.c0 + a.c1;
+    const int Cg = C / a.groups;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < a.groups) {
+        double s1 = 0.0, s2 = 0.0, g1 = 0.0, g2 = 0.0;
+        for (int q = 0; q < a.nsplit; ++q) {
+            const size_t o = (((size_t)b * a.nsplit + q) * a.groups + tid) * 2;
+            s1 += (double)a.fwd_partial[o];
+            s2 += (double)a.fwd_partial[o + 1];
+            g1 += (double)a.bwd_partial[o];
+            g2 += (double)a.bwd_partial[o + 1];
+        }
+        const double n = (double)a.HW * Cg;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+        m1_s[tid] = (float)(g1 / n);
+        m2_s[tid] = (float)(g2 / n);
+    }
+    __syncthreads();
+    const int slot = tid % slots, rl = tid / slots;
+    if (rl >= RL) return;
+    const int r_beg = blockIdx.x * rows_per_block;
+    const int r_end = min(a.HW, r_beg + rows_per_block);
+    for (int r = r_beg + rl; r < r_end; r += RL) {
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int ch = (slot * VPT + v) * VE;
+            const bool first = ch < a.c0;
+            const T* src = first ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                                 : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+            T* dst = first ? reinterpret_cast<T*>(a.dx0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                           : reinterpret_cast<T*>(a.dx1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+            const bool acc = first ? a.acc0 : a.acc1;
+            const vec_t x = *reinterpret_cast<const vec_t*>(src);
+            const vec_t dy = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(a.dy) + ((size_t)b * a.HW + r) * C + ch);
+            vec_t o;
+            if (acc) o = *reinterpret_cast<const vec_t*>(dst);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int c = ch + e;
+                const int gq = c / Cg;
+                const float xh = ((float)x[e] - mean_s[gq]) * rstd_s[gq];
+                float d = (float)dy[e];
+                if (a.silu) d *= silu_grad(xh * a.gamma[c] + a.beta[c]);
+                const float dxh = d * a.gamma[c];
+                float g = rstd_s[gq] * (dxh - m1_s[gq] - xh * m2_s[gq]);
+                if (acc) g += (float)o[e];
+                o[e] = from_f32<T>(g);
+            }
+            *reinterpret_cast<vec_t*>(dst) = o;
+        }
+    }
+}
+
+template <typename T>
+int launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st) {
+    constexpr int VE = BVec<T>::N;
+    const int C = a.c0 + a.c1;
+    MRISR_REQUIRE(C % a.groups == 0 && a.groups <= 64 && a.c0 % VE == 0 && a.c1 % VE == 0, "GroupNorm backward geometry");
+    const int nvec = C / VE;
+    int vpt = 1;
+    while (nvec / vpt > 256 || (nvec % vpt) != 0) ++vpt;
+    MRISR_REQUIRE(vpt <= 4, "GroupNorm backward: too many channels");
+    const int slots = nvec / vpt;
+    int RL = 256 / slots;
+    if (RL < 1) RL = 1;
+    const size_t smem = (size_t)2 * RL * C * sizeof(float);
+    const double act_bytes = (double)a.B * a.HW * C * sizeof(T);
+    {
+        ProfScope ps("groupnorm_bwd_stats", 0.0, 2.0 * act_bytes, st);
+        dim3 grid(a.nsplit, a.B);
+        switch (vpt) {
+            case 1: hipLaunchKernelGGL((gn_bwd_stats_kernel<T, 1>), grid, dim3(256), smem, st, a, slots, RL); break;
+            case 2: hipLaunchKernelGGL((gn_bwd_stats_kernel<T, 2>), grid, dim3(256), smem, st, a, slots, RL); break;
+            case 3: hipLaunchKernelGGL((gn_bwd_stats_kernel<T, 3>), grid, dim3(256), smem, st, a, slots, RL); break;
+            default: hipLaunchKernelGGL((gn_bwd_stats_kernel<T, 4>), grid, dim3(256), smem, st, a, slots, RL); break;
+        }
+    }
+    MRISR_CHECK_HIP(hipGetLastError());
+    int bx = 2048 / (a.B > 0 ? a.B : 1) + 1;
+    int rows_per_block = (a.HW + bx - 1) / bx;
+    if (rows_per_block < RL) rows_per_block = RL;
+    bx = (a.HW + rows_per_block - 1) / rows_per_block;
+    ProfScope ps2("groupnorm_bwd_apply", 0.0, 3.0 * act_bytes, st);
+    switch (vpt) {
+        case 1: hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 1>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
+        case 2: hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 2>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
+        case 3: hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 3>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
+        default: hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 4>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
+    }
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row, row statistics recomputed in registers.
+//   dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy * gamma;  dx (+)= into dst
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* dx,
+                                                            const float* __restrict__ gamma, int M, int C, float eps,
+                                                            int accumulate) {
+    constexpr int VE = BVec<T>::N;
+    typedef typename BVec<T>::type vec_t;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nvec = C / VE;
+    float xv[MAXV][VE], dv[MAXV][VE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const vec_t t = *reinterpret_cast<const vec_t*>(x + (size_t)row * C + vi * VE);
+            const vec_t d = *reinterpret_cast<const vec_t*>(dy + (size_t)row * C + vi * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                xv[i][e] = (float)t[e];
+                dv[i][e] = (float)d[e] * gamma[vi * VE + e];
+                s += xv[i][e];
+            }
+        }
+    }
+    const float mean = bw_wsum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float d = xv[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(bw_wsum(q) / (float)C + eps);
+    float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                xv[i][e] = (xv[i][e] - mean) * rstd;  // xhat
+                g1 += dv[i][e];
+                g2 += dv[i][e] * xv[i][e];
+            }
+        }
+    }
+    g1 = bw_wsum(g1) / (float)C;
+    g2 = bw_wsum(g2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            T* dst = dx + (size_t)row * C + vi * VE;
+            vec_t o;
+            if (accumulate) o = *reinterpret_cast<const vec_t*>(dst);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float g = rstd * (dv[i][e] - g1 - xv[i][e] * g2);
+                if (accumulate) g += (float)o[e];
+                o[e] = from_f32<T>(g);
+            }
+            *reinterpret_cast<vec_t*>(dst) = o;
+        }
+    }
+}
+
+template <typename T>
+int launch_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, int M, int C, float eps,
+                         int accumulate, hipStream_t st) {
+    constexpr int VE = BVec<T>::N;
+    MRISR_REQUIRE(C % VE == 0, "LayerNorm backward channel alignment");
+    const int need = (C / VE + 63) / 64;
+    const dim3 grid((M + 3) / 4);
+    const T* xi = reinterpret_cast<const T*>(x);
+    const T* di = reinterpret_cast<const T*>(dy);
+    T* o = reinterpret_cast<T*>(dx);
+    ProfScope ps("layernorm_bwd", 0.0, 3.0 * M * (double)C * sizeof(T), st);
+    if (need <= 1) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), grid, dim3(256), 0, st, xi, di, o, gamma, M, C, eps, accumulate);
+    else if (need <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), grid, dim3(256), 0, st, xi, di, o, gamma, M, C, eps, accumulate);
+    else if (need <= 3) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 3>), grid, dim3(256), 0, st, xi, di, o, gamma, M, C, eps, accumulate);
+    else if (need <= 5) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 5>), grid, dim3(256), 0, st, xi, di, o, gamma, M, C, eps, accumulate);
+    else MRISR_REQUIRE(false, "LayerNorm backward: row too long");
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEGLU backward.  Forward (epilogue of ff.net.0.proj): out[m][j] = u * gelu(g) with (u, g) interleaved in blocks of 16
+// in the projection's column space.  pre: [M][8C] the saved pre-activation in that interleaved layout;
+// dout: [M][4C];  dpre: [M][8C] (same interleaved layout, so the projection's dgrad uses the packed weights as is).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ pre, const T* __restrict__ dout, T* __restrict__ dpre, long long M,
+                                 int half) {
+    const long long total = M * half;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / half;
+        const int j = (int)(i - m * half);
+        const int cu = (j >> 4) * 32 + (j & 15), cg = cu + 16;
+        const float u = to_f32(pre[m * 2 * half + cu]), g = to_f32(pre[m * 2 * half + cg]);
+        const float d = to_f32(dout[i]);
+        dpre[m * 2 * half + cu] = from_f32<T>(d * gelu_erf_f(g));
+        dpre[m * 2 * half + cg] = from_f32<T>(d * u * gelu_grad(g));
+    }
+}
+template <typename T>
+int launch_geglu_bwd(const void* pre, const void* dout, void* dpre, long long M, int half, hipStream_t st) {
+    ProfScope ps("geglu_bwd", 0.0, (double)M * half * sizeof(T) * 5.0, st);
+    hipLaunchKernelGGL(geglu_bwd_kernel<T>, dim3(bw_blocks(M * half)), dim3(256), 0, st, reinterpret_cast<const T*>(pre),
+                       reinterpret_cast<const T*>(dout), reinterpret_cast<T*>(dpre), M, half);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// GEGLU forward from a stored pre-activation (training keeps `pre` for the backward instead of fusing the gate into
+// the projection's epilogue)
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ out, long long M, int half) {
+    const long long total = M * half;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / half;
+        const int j = (int)(i - m * half);
+        const int cu = (j >> 4) * 32 + (j & 15);
+        out[i] = from_f32<T>(to_f32(pre[m * 2 * half + cu]) * gelu_erf_f(to_f32(pre[m * 2 * half + cu + 16])));
+    }
+}
+template <typename T>
+int launch_geglu_fwd(const void* pre, void* out, long long M, int half, hipStream_t st) {
+    hipLaunchKernelGGL(geglu_fwd_kernel<T>, dim3(bw_blocks(M * half)), dim3(256), 0, st, reinterpret_cast<const T*>(pre),
+                       reinterpret_cast<T*>(out), M, half);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// token rows [B][N][ldx] (columns col_off .. col_off + H*hd) -> head-major [B*H][npad][dpad]; pads must be pre-zeroed
+template <typename T>
+__global__ void rows_to_heads_kernel2(const T* __restrict__ x, int ldx, int col_off, T* __restrict__ dst, int B, int N, int H, int hd,
+                                      int npad, int dpad) {
+    const long long total = (long long)B * N * H * hd;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int dd = (int)(i % hd);
+        const int h = (int)((i / hd) % H);
+        const int tok = (int)((i / ((long long)hd * H)) % N);
+        const int b = (int)(i / ((long long)hd * H * N));
+        dst[(((size_t)b * H + h) * npad + tok) * dpad + dd] = x[((size_t)b * N + tok) * ldx + col_off + h * hd + dd];
+    }
+}
+template <typename T>
+int launch_rows_to_heads(const void* x, int ldx, int col_off, void* dst, int B, int N, int H, int hd, int npad, int dpad,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(rows_to_heads_kernel2<T>, dim3(bw_blocks((long long)B * N * H * hd)), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(x), ldx, col_off, reinterpret_cast<T*>(dst), B, N, H, hd, npad, dpad);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax backward on materialised rows:  dS = scale * P * (dP - sum_k dP*P);  one wave per row.
+//   P (T) [rows][ld], dP f32 [rows][ld] -> dS (T) [rows][ld]; columns >= nk are written as 0.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, const float* __restrict__ dp, T* __restrict__ ds,
+                                                          int ld, long long rows, int nk, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* pr = p + row * ld;
+    const float* dr = dp + row * ld;
+    float s = 0.f;
+    for (int c = lane; c < nk; c += 64) s += to_f32(pr[c]) * dr[c];
+    s = bw_wsum(s);
+    T* o = ds + row * ld;
+    for (int c = lane; c < ld; c += 64) o[c] = from_f32<T>(c < nk ? scale * to_f32(pr[c]) * (dr[c] - s) : 0.f);
+}
+template <typename T>
+int launch_softmax_bwd(const void* p, const float* dp, void* ds, int ld, long long rows, int nk, float scale, hipStream_t st) {
+    ProfScope ps("softmax_bwd", 0.0, (double)rows * ld * (4.0 + 2.0 * sizeof(T)), st);
+    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const T*>(p), dp,
+                       reinterpret_cast<T*>(ds), ld, rows, nk, scale);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched transpose  dst[z][c][r] = src[z][r][c]   (R x C -> C x R per batch), 32x32 tiles through LDS.
+// Rows >= R_valid of src are treated as zero (so padded head buffers transpose to zero-padded columns).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int C, int ld_src,
+                                                        int ld_dst, long long bs_src, long long bs_dst, int r_valid) {
+    __shared__ T tile[32][33];
+    const int z = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < r_valid && r < R && c < C) ? src[(size_t)z * bs_src + (size_t)r * ld_src + c] : from_f32<T>(0.f);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)z * bs_dst + (size_t)c * ld_dst + r] = tile[tx][i];
+    }
+}
+template <typename T>
+int launch_transpose(const void* src, void* dst, int R, int C, int ld_src, int ld_dst, long long bs_src, long long bs_dst,
+                     int batch, int r_valid, hipStream_t st) {
+    ProfScope ps("transpose", 0.0, 2.0 * batch * (double)R * C * sizeof(T), st);
+    dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), R, C,
+                       ld_src, ld_dst, bs_src, bs_dst, r_valid);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LoRA weight gradients: out[c][q] += scale * sum_m P[m][c] * Q[m][q]     (P: T [M][ldp], Q: f32 [M][R], out f32)
+//   dB[n][q] = s * sum_m dY[m][n] z[m][q]   (P = dY, Q = z)      dA[q][k]^T = sum_m x[m][k] dz[m][q]  (P = x, Q = dz)
+// A block owns 64 columns and a slab of rows; float atomics fold the slabs (few, well spread addresses).
+// out_is_transposed: write out[q][c] (for dA, stored [r][K]).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int RMAX>
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const T* __restrict__ P, int ldp, const float* __restrict__ Q, int R,
+                                                         int qoff, int r, float* out, int ldo, int out_t, int M, int C,
+                                                         int rows_per_block, float scale) {
+    __shared__ float red[4][64][RMAX];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;  // 4 row interleaves
+    const int m_beg = blockIdx.y * rows_per_block, m_end = min(M, m_beg + rows_per_block);
+    float acc[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) acc[q] = 0.f;
+    if (c < C) {
+        for (int m = m_beg + sub; m < m_end; m += 4) {
+            const float pv = to_f32(P[(size_t)m * ldp + c]);
+            const float* qr = Q + (size_t)m * R + qoff;
+#pragma unroll
+            for (int q = 0; q < RMAX; ++q)
+                if (q < r) acc[q] += pv * qr[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) red[sub][threadIdx.x & 63][q] = acc[q];
+    __syncthreads();
+    if (sub == 0 && c < C) {
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+            if (q < r) {
+                const float v = scale * (red[0][threadIdx.x][q] + red[1][threadIdx.x][q] + red[2][threadIdx.x][q] + red[3][threadIdx.x][q]);
+                float* o = out_t ? out + (size_t)q * ldo + c : out + (size_t)c * ldo + q;
+                atomicAdd(o, v);
+            }
+        }
+    }
+}
+template <typename T>
+int launch_lora_wgrad(const void* P, int ldp, const float* Q, int R, int qoff, int r, float* out, int ldo, int out_t, int M, int C,
+                      float scale, hipStream_t st) {
+    MRISR_REQUIRE(r >= 1 && r <= 16, "LoRA wgrad rank (<= 16)");
+    int rows_per_block = 512;
+    dim3 grid((C + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
+    ProfScope ps("lora_wgrad", 2.0 * M * (double)C * r, (double)M * C * sizeof(T), st);
+    const T* p = reinterpret_cast<const T*>(P);
+    if (r <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<T, 4>), grid, dim3(256), 0, st, p, ldp, Q, R, qoff, r, out, ldo, out_t, M, C, rows_per_block, scale);
+    else if (r <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<T, 8>), grid, dim3(256), 0, st, p, ldp, Q, R, qoff, r, out, ldo, out_t, M, C, rows_per_block, scale);
+    else hipLaunchKernelGGL((lora_wgrad_kernel<T, 16>), grid, dim3(256), 0, st, p, ldp, Q, R, qoff, r, out, ldo, out_t, M, C, rows_per_block, scale);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 sum pool (backward of nearest x2 upsampling): dst[b][y][x][c] (+)= sum src[b][2y+dy][2x+dx][c]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void sumpool2_kernel(const T* __restrict__ src, T* dst, int B, int H, int W, int C, int accumulate) {
+    const long long total = (long long)B * H * W * C;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long p = i / C;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
+        const size_t base = (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        float v = to_f32(src[base]) + to_f32(src[base + C]) + to_f32(src[base + (size_t)2 * W * C]) + to_f32(src[base + (size_t)2 * W * C + C]);
+        if (accumulate) v += to_f32(dst[i]);
+        dst[i] = from_f32<T>(v);
+    }
+}
+template <typename T>
+int launch_sumpool2(const void* src, void* dst, int B, int H, int W, int C, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(sumpool2_kernel<T>, dim3(bw_blocks((long long)B * H * W * C)), dim3(256), 0, st, reinterpret_cast<const T*>(src),
+                       reinterpret_cast<T*>(dst), B, H, W, C, accumulate);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss: MSE(eps_hat, eps) over all elements.  pred NHWC T, target NCHW f32.  Writes dpred (NHWC T) = 2 (pred - tgt)/n and
+// accumulates the loss into loss[0] (f32, zeroed by the caller).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mse_grad_kernel(const T* __restrict__ pred, const float* __restrict__ tgt, T* __restrict__ dpred,
+                                                       float* loss, int B, int C, int H, int W, float inv_n) {
+    __shared__ float red[4];
+    const long long total = (long long)B * C * H * W;
+    float acc = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long p = i / C;
+        const long long hw = (long long)H * W;
+        const long long b = p / hw, r = p - b * hw;
+        const float d = to_f32(pred[i]) - tgt[(size_t)((b * C + c) * hw + r)];
+        acc += d * d;
+        dpred[i] = from_f32<T>(2.0f * d * inv_n);
+    }
+    acc = bw_wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+template <typename T>
+int launch_mse_grad(const void* pred, const float* tgt, void* dpred, float* loss, int B, int C, int H, int W, hipStream_t st) {
+    const long long total = (long long)B * C * H * W;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mse_grad_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const T*>(pred), tgt,
+                       reinterpret_cast<T*>(dpred), loss, B, C, H, W, 1.0f / (float)total);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser on flat f32 buffers: global grad-norm (for clip 1.0, nb ResDif c11:34) and AdamW (c11:29-33)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += g[i] * g[i];
+    acc = bw_wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+int launch_sumsq(const float* g, long long n, float* out, hipStream_t st) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, out);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// sumsq: device scalar holding the (already all-reduced) sum of squared grads; clip scale = min(1, max_norm/(norm+1e-6))
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, const float* sumsq, float grad_scale, float max_norm, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2) {
+    float clip = 1.0f;
+    if (max_norm > 0.f) {
+        const float norm = sqrtf(sumsq[0]) * grad_scale;
+        clip = fminf(1.0f, max_norm / (norm + 1e-6f));
+    }
+    const float gs = grad_scale * clip;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float pi = p[i] * (1.f - lr * wd);  // decoupled weight decay (torch.optim.AdamW)
+        pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        p[i] = pi;
+    }
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float grad_scale, float max_norm,
+                 float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, p, g, m, v, n, sumsq, grad_scale, max_norm, lr, b1, b2, eps,
+                       wd, bc1, bc2);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+#define BWD_INST(T)                                                                                                         \
+    template int launch_groupnorm_bwd<T>(const GroupNormBwdArgs&, hipStream_t);                                             \
+    template int launch_layernorm_bwd<T>(const void*, const void*, void*, const float*, int, int, float, int, hipStream_t); \
+    template int launch_geglu_bwd<T>(const void*, const void*, void*, long long, int, hipStream_t);                         \
+    template int launch_geglu_fwd<T>(const void*, void*, long long, int, hipStream_t);                                      \
+    template int launch_rows_to_heads<T>(const void*, int, int, void*, int, int, int, int, int, int, hipStream_t);         \
+    template int launch_softmax_bwd<T>(const void*, const float*, void*, int, long long, int, float, hipStream_t);          \
+    template int launch_transpose<T>(const void*, void*, int, int, int, int, long long, long long, int, int, hipStream_t);  \
+    template int launch_lora_wgrad<T>(const void*, int, const float*, int, int, int, float*, int, int, int, int, float,     \
+                                      hipStream_t);                                                                         \
+    template int launch_sumpool2<T>(const void*, void*, int, int, int, int, int, hipStream_t);                              \
+    template int launch_mse_grad<T>(const void*, const float*, void*, float*, int, int, int, int, hipStream_t);
+BWD_INST(float)
+BWD_INST(bf16)
+
+}  // namespace mrisr

@@ -68,6 +68,8 @@ struct GemmArgs {
     int lda0 = 0, lda1 = 0;    // row pitch in elements
     int conv = 0;              // 0: plain rows, 1: 3x3 conv (pad 1)
     int B = 0, Hin = 0, Win = 0, Hout = 0, Wout = 0, stride = 1, ups = 0;
+    int zstuff = 0;            // with ups = 1: the x2 image is ZERO-STUFFED (odd rows/cols are 0) instead of nearest -
+                               // the input of a stride-2 conv's dgrad (transposed convolution)
     // ---- W operand: [N][K] elements of T, K = taps*(c0+c1) ----
     const void* w = nullptr;
     int M = 0, N = 0, K = 0;
@@ -136,6 +138,48 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
 // zero-filling columns nk..ldp-1
 template <typename T>
 int launch_softmax_rows(const float* s, int ld, void* p, int ldp, long long rows, int nk, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// backward-pass kernels (bwd.hip): LoRA fine-tuning step
+// ---------------------------------------------------------------------------------------------
+struct GroupNormBwdArgs {
+    const void* x0 = nullptr;   // forward inputs (as GroupNormArgs)
+    const void* x1 = nullptr;
+    int c0 = 0, c1 = 0, B = 0, HW = 0, groups = 32;
+    float eps = 1e-5f;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    int silu = 0;
+    const void* dy = nullptr;   // [B][HW][c0+c1] T
+    void* dx0 = nullptr;        // [B][HW][c0] T
+    void* dx1 = nullptr;        // [B][HW][c1] T
+    int acc0 = 0, acc1 = 0;     // accumulate into dx0 / dx1 instead of overwriting
+    const float* fwd_partial = nullptr;  // the forward's [B][nsplit][groups][2] sums (mean / rstd are re-derived)
+    float* bwd_partial = nullptr;        // workspace of the same size
+    int nsplit = 1;
+};
+template <typename T> int launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st);
+template <typename T>
+int launch_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, int M, int C, float eps, int accumulate,
+                         hipStream_t st);
+template <typename T> int launch_geglu_bwd(const void* pre, const void* dout, void* dpre, long long M, int half, hipStream_t st);
+template <typename T> int launch_geglu_fwd(const void* pre, void* out, long long M, int half, hipStream_t st);
+template <typename T>
+int launch_rows_to_heads(const void* x, int ldx, int col_off, void* dst, int B, int N, int H, int hd, int npad, int dpad, hipStream_t st);
+template <typename T>
+int launch_softmax_bwd(const void* p, const float* dp, void* ds, int ld, long long rows, int nk, float scale, hipStream_t st);
+template <typename T>
+int launch_transpose(const void* src, void* dst, int R, int C, int ld_src, int ld_dst, long long bs_src, long long bs_dst, int batch,
+                     int r_valid, hipStream_t st);
+template <typename T>
+int launch_lora_wgrad(const void* P, int ldp, const float* Q, int R, int qoff, int r, float* out, int ldo, int out_t, int M, int C,
+                      float scale, hipStream_t st);
+template <typename T> int launch_sumpool2(const void* src, void* dst, int B, int H, int W, int C, int accumulate, hipStream_t st);
+template <typename T>
+int launch_mse_grad(const void* pred, const float* tgt, void* dpred, float* loss, int B, int C, int H, int W, hipStream_t st);
+int launch_sumsq(const float* g, long long n, float* out, hipStream_t st);
+int launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float grad_scale, float max_norm,
+                 float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // attention (attn.hip): flash-style, head-major operands written by the QKV GEMM epilogue

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
             for (int it = 0; it < A_IT; ++it) {
                 const int iy = ay[it] + ky, ix = ax[it] + kx;
                 const void* src = zero;
-                if (aok[it] && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) {
+                if (aok[it] && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && (!g.zstuff || ((iy | ix) & 1) == 0)) {
                     const size_t pix = ((size_t)ab[it] * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups);
                     src = base + pix * ld + ch + acoff[it];
                 }
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
                     const int row = it * 32 + lrow;
                     const int c = pch ^ (row & 7);
                     const int iy = ay[it] + ky, ix = ax[it] + kx;
-                    const bool ok = ab[it] >= 0 && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+                    const bool ok = ab[it] >= 0 && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && (!g.zstuff || ((iy | ix) & 1) == 0);
                     const unsigned pix = (unsigned)((ab[it] + (iy >> g.ups)) * g.Win + (ix >> g.ups));
                     avo[it] = ok ? (pix * (unsigned)ld + (unsigned)c * 8u) * 2u : BL_OOB;
                 }

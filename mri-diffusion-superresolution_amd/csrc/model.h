@@ -65,6 +65,7 @@ struct Model {
     void* cond_emb = nullptr;
     size_t cond_emb_bytes = 0;
     bool ctx_valid = false, cond_valid = false;
+    bool keep = false;  // training forward: never release arena temporaries (the backward reads them)
     // per-forward state
     float* tproj_out = nullptr;
     int t_scalar = 1;
@@ -87,6 +88,22 @@ struct Model {
                            mrisr_tensor* mid_out, hipStream_t st);
     int set_context(const mrisr_tensor* ehs, int B, int h, int w, hipStream_t st);
     int set_cond(const mrisr_tensor* cond, int L, hipStream_t st);
+
+    // ---- LoRA fine-tuning (train.hip) ----
+    struct Trainable { std::string key; long long offset, numel; int rows, cols; };
+    std::vector<Trainable> trainables;   // lora_A / lora_B tensors in flat-vector order
+    long long n_trainable = 0;
+    float* theta = nullptr;              // caller-owned flat f32 parameter vector (bound)
+    float* grad = nullptr;               // caller-owned flat f32 gradient vector (bound)
+    bool train_ready = false;
+    std::string train_ws_key;
+    std::vector<LinW*> lora_linears();   // every LinW that carries adapters, fixed order
+    int train_prepare(hipStream_t st);   // dgrad weight copies + trainable layout (after finalize)
+    int train_bind(float* theta_dev, float* grad_dev, hipStream_t st);
+    int lora_refresh(hipStream_t st);    // re-pack the adapters from theta
+    int train_step(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                   const mrisr_tensor* intrablock, int n_intra, const mrisr_tensor* target, float* loss_dev,
+                   mrisr_tensor* dsample_dbg, hipStream_t st);
 };
 
 }  // namespace mrisr

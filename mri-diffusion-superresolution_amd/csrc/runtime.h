@@ -70,6 +70,7 @@ struct ConvW {  // packed [cout][ks*ks*cin] in compute dtype, bias f32
     void* w = nullptr;
     const float* b = nullptr;
     int cin = 0, cout = 0, ks = 3;
+    void* wd = nullptr;  // training: dgrad filter bank [cin][ky'][kx'][cout] (taps flipped), compute dtype
 };
 struct LinW {  // packed [n][k] in compute dtype, bias f32 (GEGLU: interleaved)
     void* w = nullptr;
@@ -80,6 +81,14 @@ struct LinW {  // packed [n][k] in compute dtype, bias f32 (GEGLU: interleaved)
     int r = 0, R = 0, secN = 1;
     void* loraA = nullptr;
     const float* loraB = nullptr;
+    // training
+    std::vector<std::string> mod_names;  // the fused modules, in column order (e.g. attn1.to_q, to_k, to_v)
+    std::vector<int> mod_lora;           // 1 if that module carries an adapter
+    std::vector<long long> offA, offB;   // offsets of lora_A / lora_B of each module in the flat trainable vector (-1: none)
+    void* wT = nullptr;                  // [k][n] compute dtype (dgrad operand)
+    void* loraBT = nullptr;              // [R][n] compute dtype: (alpha/r) * B^T, zero outside the module's columns
+    float* loraAT = nullptr;             // [k][R] f32: A^T (epilogue operand of the dgrad)
+    float* loraB_rw = nullptr;           // writable alias of loraB (refreshed from the trainable vector)
 };
 
 struct Act {  // NHWC activation (or token rows when H*W is the token count)

@@ -147,6 +147,37 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
  * schedule's own (t_i, t_{i+1}) pair, so a truncated run reproduces the prefix of the full trajectory. */
 int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step);
 
+/* ---- LoRA fine-tuning step ---------------------------------------------------
+ * Replaces, for the UNet handle, what the reference's training cell gets from torch autograd + accelerate
+ * (notebook ResDif c11:14-41: noise_pred = unet(noisy, t, ehs).sample; loss = mse(noise_pred, noise);
+ *  accelerator.backward(loss); clip_grad_norm_(1.0); optimizer.step()).  Base weights are frozen; the trainable
+ * parameters are the peft adapters (<module>.lora_A/B.default.weight), kept by the CALLER as ONE flat f32 device
+ * vector `theta` with a gradient vector `grad` of the same length - the bucket a data-parallel host all-reduces.
+ *   prepare      - packs the transposed / tap-flipped weight copies the dX GEMMs read and lays out theta
+ *   tensor_info  - i-th adapter tensor: state-dict key, element offset in theta, shape {rows, cols}
+ *   bind         - attaches theta / grad (init_from_model: theta <- the adapters loaded with set_param)
+ *   step         - forward, loss = mean((eps_hat - target)^2) -> *loss_dev, backward; adapter gradients are ADDED to
+ *                  grad (zero it per optimiser step; accumulating several micro-batches is allowed).  target: f32
+ *                  NCHW.  pred_out (optional): eps_hat.  The model must be created with lora_fused = 1.
+ *   refresh      - re-packs the adapters from theta after the optimiser changed it
+ *   optim_sumsq  - *out_dev += sum(g^2)   (global grad norm; all-reduce it with the gradients)
+ *   optim_adamw  - torch.optim.AdamW update on flat vectors; g is first scaled by grad_scale (1/world_size after a
+ *                  sum all-reduce) and, when max_norm > 0, by min(1, max_norm / (grad_scale*sqrt(*sumsq_dev) + 1e-6))
+ *                  as torch.nn.utils.clip_grad_norm_ does; step counts from 1. */
+int mrisr_train_prepare(mrisr_model* m, void* stream);
+int64_t mrisr_train_num_trainable(const mrisr_model* m);
+int mrisr_train_num_tensors(const mrisr_model* m);
+int mrisr_train_tensor_info(const mrisr_model* m, int i, const char** key, int64_t* offset, int64_t shape[2]);
+int mrisr_train_bind(mrisr_model* m, float* theta_dev, float* grad_dev, int init_from_model, void* stream);
+int mrisr_train_refresh(mrisr_model* m, void* stream);
+int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                     const mrisr_tensor* intrablock, int n_intrablock, const mrisr_tensor* target, float* loss_dev,
+                     mrisr_tensor* pred_out, void* stream);
+int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream);
+int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, const float* sumsq_dev,
+                      float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int step, void* stream);
+
 /* ---- per-launch HIP-event profiler (bench.py roofline leg; off by default) ------------------------- */
 int mrisr_prof_enable(int on);
 int mrisr_prof_reset(void);

@@ -808,3 +808,71 @@ extern "C" int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int
     return g.splitk * 1000 == 0 ? 0 : 0;
     API_END
 }
+
+// ================================================================================================
+// LoRA fine-tuning step (train.hip)
+// ================================================================================================
+extern "C" {
+
+int mrisr_train_prepare(mrisr_model* m, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    TRY(gemm_prepare());
+    return m->train_prepare((hipStream_t)stream);
+    API_END
+}
+int64_t mrisr_train_num_trainable(const mrisr_model* m) { return m && m->train_ready ? (int64_t)m->n_trainable : -1; }
+int mrisr_train_num_tensors(const mrisr_model* m) { return m && m->train_ready ? (int)m->trainables.size() : -1; }
+int mrisr_train_tensor_info(const mrisr_model* m, int i, const char** key, int64_t* offset, int64_t shape[2]) {
+    MRISR_REQUIRE(m && m->train_ready, "call mrisr_train_prepare first");
+    MRISR_REQUIRE(i >= 0 && i < (int)m->trainables.size() && key && offset && shape, "trainable tensor index");
+    const Model::Trainable& t = m->trainables[i];
+    *key = t.key.c_str();
+    *offset = t.offset;
+    shape[0] = t.rows;
+    shape[1] = t.cols;
+    return 0;
+}
+int mrisr_train_bind(mrisr_model* m, float* theta_dev, float* grad_dev, int init_from_model, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    TRY(m->train_bind(theta_dev, grad_dev, st));
+    if (init_from_model) {
+        for (auto& t : m->trainables) {
+            const RawParam* r = m->find(t.key);
+            MRISR_REQUIRE(r && r->numel() == t.numel, "adapter tensor missing from the loaded parameters");
+            MRISR_CHECK_HIP(hipMemcpyAsync(theta_dev + t.offset, r->data->p, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    return m->lora_refresh(st);
+    API_END
+}
+int mrisr_train_refresh(mrisr_model* m, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->lora_refresh((hipStream_t)stream);
+    API_END
+}
+int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                     const mrisr_tensor* intrablock, int n_intrablock, const mrisr_tensor* target, float* loss_dev,
+                     mrisr_tensor* pred_out, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->train_step(sample, timestep, ehs, intrablock, n_intrablock, target, loss_dev, pred_out, (hipStream_t)stream);
+    API_END
+}
+int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream) {
+    MRISR_REQUIRE(g_dev && out_dev && n >= 0, "sumsq arguments");
+    return launch_sumsq(g_dev, (long long)n, out_dev, (hipStream_t)stream);
+}
+int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, const float* sumsq_dev,
+                      float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int step, void* stream) {
+    MRISR_REQUIRE(p_dev && g_dev && m_dev && v_dev && n >= 0 && step >= 1, "adamw arguments");
+    MRISR_REQUIRE(max_norm <= 0.f || sumsq_dev, "clipping needs the squared gradient norm");
+    return launch_adamw(p_dev, g_dev, m_dev, v_dev, (long long)n, sumsq_dev, grad_scale, max_norm, lr, beta1, beta2, eps,
+                        weight_decay, step, (hipStream_t)stream);
+}
+
+}  // extern "C"

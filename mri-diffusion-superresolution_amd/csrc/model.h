@@ -103,7 +103,7 @@ struct Model {
     int lora_refresh(hipStream_t st);    // re-pack the adapters from theta
     int train_step(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
                    const mrisr_tensor* intrablock, int n_intra, const mrisr_tensor* target, float* loss_dev,
-                   mrisr_tensor* dsample_dbg, hipStream_t st);
+                   mrisr_tensor* pred_out, hipStream_t st);
 };
 
 }  // namespace mrisr

@@ -85,6 +85,7 @@ struct Packer {
         ConvW c;
         const RawParam* w = need(name + ".weight");
         if (!w) return c;
+        c.name = name;
         c.cout = (int)w->shape[0];
         c.cin = (int)w->shape[1];
         c.ks = (int)w->shape[2];
@@ -371,7 +372,7 @@ template <typename T>
 static int plan_t(Model& m, int B, int h, int w, int L, hipStream_t st) {
     const mrisr_unet_cfg& c = m.cfg;
     constexpr int BK = 128 / (int)sizeof(T);
-    const bool flash = c.flash_attention && sizeof(T) == 2;
+    const bool flash = c.flash_attention && sizeof(T) == 2 && !m.keep;  // the fine-tuning step materialises P
     m.heads.clear();
     m.ws_B = B; m.ws_h = h; m.ws_w = w; m.ctx_len = L;
     m.ctx_pad = round_up(L, 64);
@@ -469,7 +470,7 @@ int Model::ensure_workspace(int B, int h, int w, int L, hipStream_t st) {
     const int div = 1 << (cfg.num_levels - 1);
     MRISR_REQUIRE(h % div == 0 && w % div == 0, "latent size must be divisible by 2^(levels-1)");
     char key[96];
-    snprintf(key, sizeof(key), "%d,%d,%d,%d", B, h, w, L);
+    snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", B, h, w, L, keep ? 1 : 0);
     if (ws_key == key) return 0;
     int rc = cfg.compute_dtype == MRISR_F32 ? plan_t<float>(*this, B, h, w, L, st) : plan_t<bf16>(*this, B, h, w, L, st);
     if (rc) return rc;

@@ -70,6 +70,7 @@ struct ConvW {  // packed [cout][ks*ks*cin] in compute dtype, bias f32
     void* w = nullptr;
     const float* b = nullptr;
     int cin = 0, cout = 0, ks = 3;
+    std::string name;    // state-dict module name (the dgrad packer re-reads the raw f32 weight)
     void* wd = nullptr;  // training: dgrad filter bank [cin][ky'][kx'][cout] (taps flipped), compute dtype
 };
 struct LinW {  // packed [n][k] in compute dtype, bias f32 (GEGLU: interleaved)

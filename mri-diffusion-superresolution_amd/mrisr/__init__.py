@@ -7,3 +7,4 @@ from .models import Adapter_XL, ControlNetModel, UNet2DConditionModel, UNetConfi
 from .pipeline import (Sampler, decode_to_vis, get_res_shifting_latents, log_validation,  # noqa: F401
                        prepare_condition_image)
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
+from .train import LoRATrainer, cosine_lr  # noqa: F401

@@ -39,3 +39,14 @@ def sum_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_reduce_sum_(flat: torch.Tensor, group=None) -> int:
+    """The ONE exchange step of the data-parallel fine-tune: in-place SUM over ranks of the flat adapter
+    gradient bucket (RCCL ``ncclAllReduce`` on GPUs; gloo in the CPU tests).  Returns the world size, which the optimiser
+    folds in as ``grad_scale = 1 / world``.  Without a process group it is the identity (world 1)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return dist.get_world_size(group)

@@ -1,0 +1,170 @@
+"""GPU: the LoRA fine-tuning step (forward + MSE + backward + clip + AdamW) of libmrisr against torch autograd on the CPU
+oracle.  f32 path: 1e-3 relative on every adapter gradient; bf16: relative-L2 bound on the bucket."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from oracle import unet as ou
+    cfg = ou.TINY
+    up = ou.init_unet_params(cfg, seed=111, perturb_norm=True)
+    lora = ou.init_lora_params(up, rank=4, seed=113)
+    return cfg, up, lora
+
+
+def oracle_grads(cfg, up, lora, x, t, ctx, target, lora_scale, intra=None):
+    from oracle import unet as ou
+    lp = {k: v.clone().requires_grad_(True) for k, v in lora.items()}
+    with torch.enable_grad():
+        pred = ou.unet_forward({**up, **lp}, cfg, x, t, ctx, down_intrablock_additional_residuals=intra, lora_scale=lora_scale)
+        loss = torch.nn.functional.mse_loss(pred, target)
+        loss.backward()
+    return pred.detach(), float(loss.detach()), {k: v.grad for k, v in lp.items()}
+
+
+def make_batch(cfg, B, h, seed, L=77):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 4, h, h), generator=g)
+    ctx = torch.randn((B, L, cfg.cross_attention_dim), generator=g)
+    tgt = torch.randn((B, 4, h, h), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    return x, t, ctx, tgt
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+def test_lora_gradients_match_autograd(tiny, dt, tol):
+    import mrisr
+    from oracle import unet as ou
+    cfg, up, lora = tiny
+    B, h = 2, 16
+    x, t, ctx, tgt = make_batch(cfg, B, h, 21)
+    pred_ref, loss_ref, gref = oracle_grads(cfg, up, lora, x, t, ctx, tgt, lora_scale=2.0)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype=dt, lora_rank=4, lora_alpha=8, lora_fused=True)
+    net.load_state_dict({**up, **lora})
+    tr = mrisr.LoRATrainer(net)
+    assert tr.num_trainable == ou.count_params(lora)
+    assert {k for k, _, _ in tr.layout} == set(lora)
+    # bound theta reproduces the loaded adapters
+    for k, v in tr.state_dict().items():
+        assert torch.equal(v.cpu(), lora[k])
+    tr.zero_grad()
+    loss, pred = tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), return_pred=True)
+    assert rel(pred, pred_ref) < tol
+    assert abs(float(loss) - loss_ref) / loss_ref < tol
+    grads = tr.gradients()
+    flat_ref = torch.cat([gref[k].reshape(-1) for k, _, _ in tr.layout])
+    assert rel(tr.grad, flat_ref) < tol, rel(tr.grad, flat_ref)
+    if dt == "f32":
+        worst = max((rel(grads[k], gref[k]), k) for k in gref)
+        assert worst[0] < 1e-3, worst
+    # gradients ACCUMULATE across micro-batches
+    tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    assert rel(tr.grad, 2 * flat_ref) < tol
+    # inference on the same handle still works after a training step (workspace re-planned, flash path back on)
+    out = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+    assert rel(out, pred_ref) < (1e-3 if dt == "f32" else 5e-2)
+
+
+def test_training_with_adapter_features_and_scalar_timestep(tiny):
+    """cfg 3 shape: T2I-Adapter features enter as constants; timestep given as a 0-dim tensor."""
+    import mrisr
+    cfg, up, lora = tiny
+    B, h = 1, 8
+    x, _, ctx, tgt = make_batch(cfg, B, h, 22, L=16)
+    t = torch.tensor(417)
+    g = torch.Generator().manual_seed(5)
+    intra = [0.3 * torch.randn((B, c, h >> i, h >> i), generator=g) for i, c in enumerate(cfg.block_out_channels)]
+    pred_ref, loss_ref, gref = oracle_grads(cfg, up, lora, x, t, ctx, tgt, 1.0, intra=intra)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+    net.load_state_dict({**up, **lora})
+    tr = mrisr.LoRATrainer(net)
+    loss, pred = tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(),
+                                     down_intrablock_additional_residuals=[f.cuda() for f in intra], return_pred=True)
+    assert rel(pred, pred_ref) < 1e-3
+    grads = tr.gradients()
+    worst = max((rel(grads[k], gref[k]), k) for k in gref)
+    assert worst[0] < 1e-3, worst
+
+
+def test_adamw_clip_step_matches_torch(tiny):
+    """Three full steps (clip 1.0 + AdamW, reference nb:ResDif c11:29-34) track torch.optim.AdamW on the oracle."""
+    import mrisr
+    from oracle import unet as ou
+    cfg, up, lora = tiny
+    B, h = 2, 8
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+    net.load_state_dict({**up, **lora})
+    tr = mrisr.LoRATrainer(net, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
+    lp = {k: v.clone().requires_grad_(True) for k, v in lora.items()}
+    opt = torch.optim.AdamW(list(lp.values()), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    for step in range(3):
+        x, t, ctx, tgt = make_batch(cfg, B, h, 30 + step, L=16)
+        tgt = 200.0 * tgt  # large loss -> the clip is active
+        with torch.enable_grad():
+            pred = ou.unet_forward({**up, **lp}, cfg, x, t, ctx, lora_scale=1.0)
+            loss_ref = torch.nn.functional.mse_loss(pred, tgt)
+            opt.zero_grad()
+            loss_ref.backward()
+        norm_ref = float(torch.nn.utils.clip_grad_norm_(list(lp.values()), 1.0))
+        opt.step()
+        loss = tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+        assert abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-3
+        assert norm_ref > 1.0 and abs(tr.grad_norm() - norm_ref) / norm_ref < 1e-3
+        sd = tr.state_dict()
+        worst = max((rel(sd[k], lp[k]), k) for k in lp)
+        assert worst[0] < 1e-3, (step, worst)
+    # the updated adapters are what inference on the handle now uses
+    x, t, ctx, _ = make_batch(cfg, B, h, 40, L=16)
+    with torch.no_grad():
+        ref = ou.unet_forward({**up, **{k: v.detach() for k, v in lp.items()}}, cfg, x, t, ctx, lora_scale=1.0)
+    assert rel(net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample, ref) < 1e-3
+
+
+def test_optimizer_kernels_against_torch():
+    from mrisr import _lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(3)
+    n = 100003
+    p = torch.randn(n, generator=g).cuda()
+    gr = (0.01 * torch.randn(n, generator=g)).cuda()
+    m, v = torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    pr = p.clone().cpu().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=3e-3, weight_decay=0.05)
+    ss = torch.zeros(1).cuda()
+    lib = L.lib()
+    for step in range(1, 4):
+        pr.grad = gr.cpu().clone() / 2  # grad_scale = 1/2 (two ranks summed)
+        torch.nn.utils.clip_grad_norm_([pr], 0.5)
+        opt.step()
+        ss.zero_()
+        L.check(lib.mrisr_optim_sumsq(C.c_void_p(gr.data_ptr()), C.c_int64(n), C.c_void_p(ss.data_ptr()), L.stream_ptr()))
+        assert abs(float(ss) - float((gr.double() ** 2).sum())) / float(ss) < 1e-5
+        L.check(lib.mrisr_optim_adamw(C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(m.data_ptr()),
+                                      C.c_void_p(v.data_ptr()), C.c_int64(n), C.c_void_p(ss.data_ptr()), C.c_float(0.5),
+                                      C.c_float(0.5), C.c_float(3e-3), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+                                      C.c_float(0.05), C.c_int(step), L.stream_ptr()))
+        assert rel(p, pr) < 1e-5
+
+
+def test_train_errors(tiny):
+    import mrisr
+    cfg, up, lora = tiny
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=False)
+    net.load_state_dict({**up, **lora})
+    with pytest.raises(mrisr.MrisrError, match="un-merged"):
+        mrisr.LoRATrainer(net)
+    net2 = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+    net2.load_state_dict({**up, **lora})
+    tr = mrisr.LoRATrainer(net2)
+    x, t, ctx, tgt = make_batch(cfg, 1, 8, 50, L=16)
+    with pytest.raises(mrisr.MrisrError, match="target"):
+        tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt[:, :2].contiguous().cuda())

@@ -6,6 +6,12 @@
 
 namespace mrisr {
 
+#define TRY_(expr)           \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
 template <typename T> struct BVec;
 template <> struct BVec<bf16> { static constexpr int N = 8; typedef bf16x8 type; };
 template <> struct BVec<float> { static constexpr int N = 4; typedef f32x4 type; };
@@ -402,11 +408,70 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
     T* o = ds + row * ld;
     for (int c = lane; c < ld; c += 64) o[c] = from_f32<T>(c < nk ? scale * to_f32(pr[c]) * (dr[c] - s) : 0.f);
 }
+// vectorised variant: P and dP rows in registers, 16-byte accesses.  Needs ld % 4 == 0, ld <= 256 * MAXV.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const T* __restrict__ p, const float* __restrict__ dp, T* __restrict__ ds,
+                                                              int ld, long long rows, int nk, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* pr = p + row * ld;
+    const float* dr = dp + row * ld;
+    f32x4 pv[MAXV], dv[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < ld) {
+            dv[i] = *reinterpret_cast<const f32x4*>(dr + c);
+            if constexpr (sizeof(T) == 2) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(pr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv[i][e] = (float)t[e];
+            } else {
+                pv[i] = *reinterpret_cast<const f32x4*>(pr + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < nk) s += pv[i][e] * dv[i][e];
+        }
+    }
+    s = bw_wsum(s);
+    T* o = ds + row * ld;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < ld) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = c + e < nk ? scale * pv[i][e] * (dv[i][e] - s) : 0.f;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (bf16)r[e];
+                *reinterpret_cast<bf16x4*>(o + c) = t;
+            } else {
+                *reinterpret_cast<f32x4*>(o + c) = r;
+            }
+        }
+    }
+}
 template <typename T>
 int launch_softmax_bwd(const void* p, const float* dp, void* ds, int ld, long long rows, int nk, float scale, hipStream_t st) {
     ProfScope ps("softmax_bwd", 0.0, (double)rows * ld * (4.0 + 2.0 * sizeof(T)), st);
-    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const T*>(p), dp,
-                       reinterpret_cast<T*>(ds), ld, rows, nk, scale);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const T* pp = reinterpret_cast<const T*>(p);
+    T* dd = reinterpret_cast<T*>(ds);
+    if (ld % 4 == 0 && ld <= 4096) {
+        const int need = (ld / 4 + 63) / 64;
+        if (need <= 1) hipLaunchKernelGGL((softmax_bwd_vec_kernel<T, 1>), grid, dim3(256), 0, st, pp, dp, dd, ld, rows, nk, scale);
+        else if (need <= 2) hipLaunchKernelGGL((softmax_bwd_vec_kernel<T, 2>), grid, dim3(256), 0, st, pp, dp, dd, ld, rows, nk, scale);
+        else if (need <= 4) hipLaunchKernelGGL((softmax_bwd_vec_kernel<T, 4>), grid, dim3(256), 0, st, pp, dp, dd, ld, rows, nk, scale);
+        else if (need <= 8) hipLaunchKernelGGL((softmax_bwd_vec_kernel<T, 8>), grid, dim3(256), 0, st, pp, dp, dd, ld, rows, nk, scale);
+        else hipLaunchKernelGGL((softmax_bwd_vec_kernel<T, 16>), grid, dim3(256), 0, st, pp, dp, dd, ld, rows, nk, scale);
+    } else {
+        hipLaunchKernelGGL(softmax_bwd_kernel<T>, grid, dim3(256), 0, st, pp, dp, dd, ld, rows, nk, scale);
+    }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -432,68 +497,240 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
         if (c < C && r < R) dst[(size_t)z * bs_dst + (size_t)c * ld_dst + r] = tile[tx][i];
     }
 }
+// 64x64 tiles, 16-byte global accesses on both sides (needs R, C, pitches and batch strides to be multiples of a vector)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int C, int ld_src,
+                                                            int ld_dst, long long bs_src, long long bs_dst, int r_valid) {
+    constexpr int VE = BVec<T>::N;
+    constexpr int VPR = 64 / VE;
+    constexpr int LDT = 64 + (sizeof(T) == 2 ? 2 : 1);
+    typedef typename BVec<T>::type vec_t;
+    __shared__ T tile[64 * LDT];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    src += (size_t)blockIdx.z * bs_src;
+    dst += (size_t)blockIdx.z * bs_dst;
+    for (int idx = threadIdx.x; idx < 64 * VPR; idx += 256) {
+        const int row = idx / VPR, cv = idx - row * VPR;
+        const int r = r0 + row, c = c0 + cv * VE;
+        vec_t v;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = from_f32<T>(0.f);
+        if (r < R && r < r_valid && c < C) v = *reinterpret_cast<const vec_t*>(src + (size_t)r * ld_src + c);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) tile[row * LDT + cv * VE + e] = v[e];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * VPR; idx += 256) {
+        const int crow = idx / VPR, g = idx - crow * VPR;
+        const int c = c0 + crow, r = r0 + g * VE;
+        if (c < C && r < R) {
+            vec_t v;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = tile[(g * VE + e) * LDT + crow];
+            *reinterpret_cast<vec_t*>(dst + (size_t)c * ld_dst + r) = v;
+        }
+    }
+}
 template <typename T>
 int launch_transpose(const void* src, void* dst, int R, int C, int ld_src, int ld_dst, long long bs_src, long long bs_dst,
                      int batch, int r_valid, hipStream_t st) {
+    constexpr int VE = BVec<T>::N;
     ProfScope ps("transpose", 0.0, 2.0 * batch * (double)R * C * sizeof(T), st);
-    dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
-    hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), R, C,
-                       ld_src, ld_dst, bs_src, bs_dst, r_valid);
+    const bool vec = R % VE == 0 && C % VE == 0 && ld_src % VE == 0 && ld_dst % VE == 0 && bs_src % VE == 0 && bs_dst % VE == 0 &&
+                     ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0;
+    if (vec) {
+        dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+        hipLaunchKernelGGL(transpose_vec_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), R,
+                           C, ld_src, ld_dst, bs_src, bs_dst, r_valid);
+    } else {
+        dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
+        hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, st, reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), R, C,
+                           ld_src, ld_dst, bs_src, bs_dst, r_valid);
+    }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// LoRA weight gradients: out[c][q] += scale * sum_m P[m][c] * Q[m][q]     (P: T [M][ldp], Q: f32 [M][R], out f32)
-//   dB[n][q] = s * sum_m dY[m][n] z[m][q]   (P = dY, Q = z)      dA[q][k]^T = sum_m x[m][k] dz[m][q]  (P = x, Q = dz)
-// A block owns 64 columns and a slab of rows; float atomics fold the slabs (few, well spread addresses).
-// out_is_transposed: write out[q][c] (for dA, stored [r][K]).
+// LoRA weight gradients: rank-r outer-product sums over the M rows of an activation, one streaming pass.
+//   mode 0 (dB): out_j[c'][q] += scale * sum_m P[m][c] Q[m][j*r+q],  j = c / secN, c' = c - j*secN   (P = dY, Q = z)
+//   mode 1 (dA): out_j[q][c]  += scale * sum_m P[m][c] Q[m][j*r+q]   for every fused module j         (P = x,  Q = dz)
+// HBM-bound (8*NQ FMAs per 16 bytes of P).  A block owns a slab of rows and up to 256 16-byte channel chunks; its
+// threads tile (row interleave, chunk) so a wave reads contiguous row segments, four rows in flight per thread; Q rows
+// are broadcast loads.  The row interleaves fold through LDS atomics into one partial tile per block (plain stores,
+// no global atomics: a thousand blocks hitting the same few KB serialise in L2), then a second tiny kernel sums the
+// partial tiles and adds them to the gradient vector.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int RMAX>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(const T* __restrict__ P, int ldp, const float* __restrict__ Q, int R,
-                                                         int qoff, int r, float* out, int ldo, int out_t, int M, int C,
-                                                         int rows_per_block, float scale) {
-    __shared__ float red[4][64][RMAX];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;  // 4 row interleaves
-    const int m_beg = blockIdx.y * rows_per_block, m_end = min(M, m_beg + rows_per_block);
-    float acc[RMAX];
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) acc[q] = 0.f;
-    if (c < C) {
-        for (int m = m_beg + sub; m < m_end; m += 4) {
-            const float pv = to_f32(P[(size_t)m * ldp + c]);
-            const float* qr = Q + (size_t)m * R + qoff;
-#pragma unroll
-            for (int q = 0; q < RMAX; ++q)
-                if (q < r) acc[q] += pv * qr[q];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) red[sub][threadIdx.x & 63][q] = acc[q];
-    __syncthreads();
-    if (sub == 0 && c < C) {
-#pragma unroll
-        for (int q = 0; q < RMAX; ++q) {
-            if (q < r) {
-                const float v = scale * (red[0][threadIdx.x][q] + red[1][threadIdx.x][q] + red[2][threadIdx.x][q] + red[3][threadIdx.x][q]);
-                float* o = out_t ? out + (size_t)q * ldo + c : out + (size_t)c * ldo + q;
-                atomicAdd(o, v);
-            }
-        }
+struct LoraWgradArgs {
+    const void* P = nullptr;
+    int ldp = 0;
+    const float* Q = nullptr;
+    int ldq = 0;
+    int M = 0, C = 0, mode = 0, r = 0, nmod = 1, secN = 0, qbase = 0;
+    float* out[3] = {nullptr, nullptr, nullptr};
+    float scale = 1.0f;
+    float* partial = nullptr;  // [gy][gx * cxb * VE * NQ]
+    int cxb = 0, RL = 1, rpb = 0, gx = 1, gy = 1;
+};
+static void lora_wgrad_geom(LoraWgradArgs& a, int VE) {
+    const int cx = a.C / VE;
+    a.gx = (cx + 255) / 256;
+    a.cxb = (cx + a.gx - 1) / a.gx;
+    a.RL = 256 / a.cxb;
+    a.rpb = a.RL * 16;
+    a.gy = (a.M + a.rpb - 1) / a.rpb;
+    if (a.gy > 512) {
+        a.rpb = ((a.M + 511) / 512 + a.RL - 1) / a.RL * a.RL;
+        a.gy = (a.M + a.rpb - 1) / a.rpb;
     }
 }
+size_t lora_wgrad_scratch_bytes(int M, int C, int nq, int elem_size) {
+    LoraWgradArgs a;
+    a.M = M; a.C = C;
+    const int VE = 16 / elem_size;
+    lora_wgrad_geom(a, VE);
+    return (size_t)a.gy * a.gx * a.cxb * VE * nq * sizeof(float);
+}
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const LoraWgradArgs a) {
+    constexpr int VE = BVec<T>::N;
+    typedef typename BVec<T>::type vec_t;
+    extern __shared__ float red[];  // [cxb * VE * NQ] when RL > 1
+    const int ch = threadIdx.x % a.cxb, rs = threadIdx.x / a.cxb;
+    const int c0 = (blockIdx.x * a.cxb + ch) * VE;
+    const bool live = rs < a.RL && c0 < a.C;
+    const int qb = a.mode == 0 ? (live ? (c0 / a.secN) * a.r : 0) : a.qbase;
+    const int tile = a.cxb * VE * NQ;
+    if (a.RL > 1)
+        for (int i = threadIdx.x; i < tile; i += 256) red[i] = 0.f;
+    float acc[VE][NQ];
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[e][q] = 0.f;
+    const int m_beg = blockIdx.y * a.rpb, m_end = min(a.M, m_beg + a.rpb);
+    if (live) {
+        const T* p = reinterpret_cast<const T*>(a.P) + c0;
+        const float* qp = a.Q + qb;
+        auto fma_row = [&](const vec_t& pv, const float* qr) {
+            float qv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(qr + q);
+                qv[q] = t[0]; qv[q + 1] = t[1]; qv[q + 2] = t[2]; qv[q + 3] = t[3];
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float x = (float)pv[e];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[e][q] += x * qv[q];
+            }
+        };
+        int m = m_beg + rs;
+        const int step = a.RL;
+        for (; m + 3 * step < m_end; m += 4 * step) {
+            const vec_t p0 = *reinterpret_cast<const vec_t*>(p + (size_t)m * a.ldp);
+            const vec_t p1 = *reinterpret_cast<const vec_t*>(p + (size_t)(m + step) * a.ldp);
+            const vec_t p2 = *reinterpret_cast<const vec_t*>(p + (size_t)(m + 2 * step) * a.ldp);
+            const vec_t p3 = *reinterpret_cast<const vec_t*>(p + (size_t)(m + 3 * step) * a.ldp);
+            fma_row(p0, qp + (size_t)m * a.ldq);
+            fma_row(p1, qp + (size_t)(m + step) * a.ldq);
+            fma_row(p2, qp + (size_t)(m + 2 * step) * a.ldq);
+            fma_row(p3, qp + (size_t)(m + 3 * step) * a.ldq);
+        }
+        for (; m < m_end; m += step) fma_row(*reinterpret_cast<const vec_t*>(p + (size_t)m * a.ldp), qp + (size_t)m * a.ldq);
+    }
+    float* dst = a.partial + ((size_t)blockIdx.y * a.gx + blockIdx.x) * tile;
+    if (a.RL == 1) {
+        if (threadIdx.x < a.cxb) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+#pragma unroll
+                for (int q = 0; q < NQ; q += 4)
+                    *reinterpret_cast<f32x4*>(dst + (ch * VE + e) * NQ + q) = f32x4{acc[e][q], acc[e][q + 1], acc[e][q + 2], acc[e][q + 3]};
+        }
+        return;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) atomicAdd(&red[(ch * VE + e) * NQ + q], acc[e][q]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tile; i += 256) dst[i] = red[i];
+}
+// sums the partial tiles and adds them into the gradient tensors: 16 outputs x 16 row-slab groups per block (the
+// partial rows are ~100 dependent-latency loads apart if one thread walks them alone)
+__global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(const LoraWgradArgs a, int VE, int NQ) {
+    __shared__ float red[16][17];
+    const int tile = a.cxb * VE * NQ;
+    const int total = a.gx * tile;
+    const int ol = threadIdx.x & 15, yg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ol;
+    float s = 0.f;
+    if (i < total) {
+        const float* p = a.partial + i;
+        const size_t pitch = (size_t)a.gx * tile;
+        int y = yg;
+        for (; y + 48 < a.gy; y += 64) s += (p[y * pitch] + p[(y + 16) * pitch]) + (p[(y + 32) * pitch] + p[(y + 48) * pitch]);
+        for (; y < a.gy; y += 16) s += p[y * pitch];
+    }
+    red[yg][ol] = s;
+    __syncthreads();
+    if (threadIdx.x >= 16 || i >= total) return;
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][ol];
+    const int bx = i / tile, il = i - bx * tile;
+    const int q = il % NQ, cl = il / NQ;
+    const int c = bx * a.cxb * VE + cl;
+    if (c >= a.C) return;
+    s *= a.scale;
+    if (a.mode == 0) {
+        const int j = c / a.secN;
+        if (a.out[j]) a.out[j][(size_t)(c - j * a.secN) * a.r + q] += s;
+    } else {
+        const int qq = a.qbase + q, j = qq / a.r;
+        if (a.out[j]) a.out[j][(size_t)(qq - j * a.r) * a.C + c] += s;
+    }
+}
+// mode 0: dB of the fused modules of one linear (P = dY [M][nmod*secN], Q = z [M][nmod*r]);
+// mode 1: dA (P = x [M][k], Q = dz [M][nmod*r]).  out[j] == nullptr: module j has no adapter.
+// scratch: lora_wgrad_scratch_bytes(M, C, nmod*r, sizeof(T)) bytes.
 template <typename T>
-int launch_lora_wgrad(const void* P, int ldp, const float* Q, int R, int qoff, int r, float* out, int ldo, int out_t, int M, int C,
-                      float scale, hipStream_t st) {
-    MRISR_REQUIRE(r >= 1 && r <= 16, "LoRA wgrad rank (<= 16)");
-    int rows_per_block = 512;
-    dim3 grid((C + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
-    ProfScope ps("lora_wgrad", 2.0 * M * (double)C * r, (double)M * C * sizeof(T), st);
-    const T* p = reinterpret_cast<const T*>(P);
-    if (r <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<T, 4>), grid, dim3(256), 0, st, p, ldp, Q, R, qoff, r, out, ldo, out_t, M, C, rows_per_block, scale);
-    else if (r <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<T, 8>), grid, dim3(256), 0, st, p, ldp, Q, R, qoff, r, out, ldo, out_t, M, C, rows_per_block, scale);
-    else hipLaunchKernelGGL((lora_wgrad_kernel<T, 16>), grid, dim3(256), 0, st, p, ldp, Q, R, qoff, r, out, ldo, out_t, M, C, rows_per_block, scale);
+int launch_lora_wgrad(const void* P, int ldp, const float* Q, int ldq, int M, int C, int mode, int r, int nmod, int secN,
+                      float* const out[3], float scale, float* scratch, hipStream_t st) {
+    constexpr int VE = BVec<T>::N;
+    MRISR_REQUIRE(r % 4 == 0 && r >= 4 && r <= 16 && nmod >= 1 && nmod <= 3, "LoRA wgrad: rank 4/8/12/16, <= 3 fused modules");
+    MRISR_REQUIRE(C % VE == 0 && ldp % VE == 0 && ldq % 4 == 0 && (mode == 1 || secN % VE == 0) && scratch, "LoRA wgrad alignment");
+    LoraWgradArgs a;
+    a.P = P; a.ldp = ldp; a.Q = Q; a.ldq = ldq; a.M = M; a.C = C; a.mode = mode; a.r = r; a.nmod = nmod; a.secN = secN;
+    for (int j = 0; j < 3; ++j) a.out[j] = j < nmod ? out[j] : nullptr;
+    a.scale = scale;
+    a.partial = scratch;
+    lora_wgrad_geom(a, VE);
+    const dim3 grid(a.gx, a.gy);
+    const int R = nmod * r;
+    ProfScope ps("lora_wgrad", 2.0 * M * (double)C * (mode ? R : r), (double)M * C * sizeof(T), st);
+    auto go = [&](int nq, int qbase) -> int {
+        a.qbase = qbase;
+        const size_t smem = a.RL > 1 ? (size_t)a.cxb * VE * nq * sizeof(float) : 0;
+        MRISR_REQUIRE(smem <= 65536, "LoRA wgrad: LDS tile");
+        switch (nq) {
+            case 4: hipLaunchKernelGGL((lora_wgrad_kernel<T, 4>), grid, dim3(256), smem, st, a); break;
+            case 8: hipLaunchKernelGGL((lora_wgrad_kernel<T, 8>), grid, dim3(256), smem, st, a); break;
+            case 12: hipLaunchKernelGGL((lora_wgrad_kernel<T, 12>), grid, dim3(256), smem, st, a); break;
+            default: hipLaunchKernelGGL((lora_wgrad_kernel<T, 16>), grid, dim3(256), smem, st, a); break;
+        }
+        const int total = a.gx * a.cxb * VE * nq;
+        hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, a, VE, nq);
+        return 0;
+    };
+    if (mode == 0) TRY_(go(r, 0));
+    else if (R <= 16) TRY_(go(R, 0));
+    else for (int j = 0; j < nmod; ++j) TRY_(go(r, j * r));  // wide adapters: one pass per module
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -614,8 +851,8 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long long n, cons
     template int launch_rows_to_heads<T>(const void*, int, int, void*, int, int, int, int, int, int, hipStream_t);         \
     template int launch_softmax_bwd<T>(const void*, const float*, void*, int, long long, int, float, hipStream_t);          \
     template int launch_transpose<T>(const void*, void*, int, int, int, int, long long, long long, int, int, hipStream_t);  \
-    template int launch_lora_wgrad<T>(const void*, int, const float*, int, int, int, float*, int, int, int, int, float,     \
-                                      hipStream_t);                                                                         \
+    template int launch_lora_wgrad<T>(const void*, int, const float*, int, int, int, int, int, int, int, float* const[3],   \
+                                      float, float*, hipStream_t);                                                          \
     template int launch_sumpool2<T>(const void*, void*, int, int, int, int, int, hipStream_t);                              \
     template int launch_mse_grad<T>(const void*, const float*, void*, float*, int, int, int, int, hipStream_t);
 BWD_INST(float)

@@ -172,8 +172,9 @@ template <typename T>
 int launch_transpose(const void* src, void* dst, int R, int C, int ld_src, int ld_dst, long long bs_src, long long bs_dst, int batch,
                      int r_valid, hipStream_t st);
 template <typename T>
-int launch_lora_wgrad(const void* P, int ldp, const float* Q, int R, int qoff, int r, float* out, int ldo, int out_t, int M, int C,
-                      float scale, hipStream_t st);
+int launch_lora_wgrad(const void* P, int ldp, const float* Q, int ldq, int M, int C, int mode, int r, int nmod, int secN,
+                      float* const out[3], float scale, float* scratch, hipStream_t st);
+size_t lora_wgrad_scratch_bytes(int M, int C, int nq, int elem_size);
 template <typename T> int launch_sumpool2(const void* src, void* dst, int B, int H, int W, int C, int accumulate, hipStream_t st);
 template <typename T>
 int launch_mse_grad(const void* pred, const float* tgt, void* dpred, float* loss, int B, int C, int H, int W, hipStream_t st);

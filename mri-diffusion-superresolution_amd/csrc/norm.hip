@@ -303,12 +303,77 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = lane; c < ldp; c += 64) pr[c] = from_f32<T>(c < nk ? expf(sr[c] - mx) * inv : 0.f);
 }
 
+// vectorised variant: the whole row lives in registers (one global read, one exp per element), 16-byte accesses.
+// Needs ld == ldp, ld % 4 == 0, ld <= 256 * MAXV.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_vec_kernel(const float* __restrict__ s, int ld, T* __restrict__ p, long long rows,
+                                                               int nk) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * ld;
+    f32x4 v[MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < ld) {
+            v[i] = *reinterpret_cast<const f32x4*>(sr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c + e >= nk) v[i][e] = -INFINITY;
+                mx = fmaxf(mx, v[i][e]);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < ld) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = expf(v[i][e] - mx);  // exp(-inf) = 0 for the masked tail
+                sum += v[i][e];
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* pr = p + row * ld;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < ld) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[i][e] * inv);
+                *reinterpret_cast<bf16x4*>(pr + c) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(pr + c) = v[i] * inv;
+            }
+        }
+    }
+}
+
 template <typename T>
 int launch_softmax_rows(const float* s, int ld, void* p, int ldp, long long rows, int nk, hipStream_t st) {
     // NOTE: p may alias s only when sizeof(T) == 4 and ldp == ld (each lane rewrites what it alone read)
     const dim3 grid((unsigned)((rows + 3) / 4));
     ProfScope ps("softmax_rows", 0.0, (double)rows * ld * (4.0 + sizeof(T)), st);
-    hipLaunchKernelGGL(softmax_rows_kernel<T>, grid, dim3(256), 0, st, s, ld, reinterpret_cast<T*>(p), ldp, rows, nk);
+    T* pp = reinterpret_cast<T*>(p);
+    if (ld == ldp && ld % 4 == 0 && ld <= 4096 && nk >= 1) {
+        const int need = (ld / 4 + 63) / 64;
+        if (need <= 1) hipLaunchKernelGGL((softmax_rows_vec_kernel<T, 1>), grid, dim3(256), 0, st, s, ld, pp, rows, nk);
+        else if (need <= 2) hipLaunchKernelGGL((softmax_rows_vec_kernel<T, 2>), grid, dim3(256), 0, st, s, ld, pp, rows, nk);
+        else if (need <= 4) hipLaunchKernelGGL((softmax_rows_vec_kernel<T, 4>), grid, dim3(256), 0, st, s, ld, pp, rows, nk);
+        else if (need <= 8) hipLaunchKernelGGL((softmax_rows_vec_kernel<T, 8>), grid, dim3(256), 0, st, s, ld, pp, rows, nk);
+        else hipLaunchKernelGGL((softmax_rows_vec_kernel<T, 16>), grid, dim3(256), 0, st, s, ld, pp, rows, nk);
+    } else {
+        hipLaunchKernelGGL(softmax_rows_kernel<T>, grid, dim3(256), 0, st, s, ld, pp, ldp, rows, nk);
+    }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -6,6 +6,7 @@
 // replayed in reverse.  Base weights are frozen, so the backward is dX everywhere (dgrad GEMMs on transposed / tap-flipped
 // weight copies packed once by train_prepare) plus the rank-r wgrads of the adapters, accumulated with float atomics
 // into the caller's flat f32 gradient vector (which the host all-reduces over RCCL before the optimiser step).
+#include <algorithm>
 #include <functional>
 #include <set>
 
@@ -264,15 +265,20 @@ struct Trainer : Runner<T> {
         if (lw.R) {
             MRISR_REQUIRE(z && lw.loraBT && lw.loraAT && m.grad, "adapter backward state");
             dz = static_cast<float*>(alloc((size_t)M * lw.R * sizeof(float)));
-            if (!dz) return 7;
+            const size_t sb = std::max(lora_wgrad_scratch_bytes(M, lw.n, lw.R, sizeof(T)), lora_wgrad_scratch_bytes(M, lw.k, lw.R, sizeof(T)));
+            float* scratch = static_cast<float*>(alloc(sb));
+            if (!dz || !scratch) return 7;
             if (!dry) {
                 TRY(launch_lora_down<T>(dY, ldy, lw.loraBT, dz, M, lw.n, lw.R, st));
-                for (size_t j = 0; j < lw.mod_names.size(); ++j) {
+                const int nmod = (int)lw.mod_names.size();
+                float *oA[3] = {nullptr, nullptr, nullptr}, *oB[3] = {nullptr, nullptr, nullptr};
+                for (int j = 0; j < nmod; ++j) {
                     if (!lw.mod_lora[j]) continue;
-                    const T* dYj = reinterpret_cast<const T*>(dY) + (size_t)j * lw.secN;
-                    TRY(launch_lora_wgrad<T>(dYj, ldy, z, lw.R, (int)j * lw.r, lw.r, m.grad + lw.offB[j], lw.r, 0, M, lw.secN, m.lora_scale, st));
-                    TRY(launch_lora_wgrad<T>(x, ldx, dz, lw.R, (int)j * lw.r, lw.r, m.grad + lw.offA[j], lw.k, 1, M, lw.k, 1.0f, st));
+                    oA[j] = m.grad + lw.offA[j];
+                    oB[j] = m.grad + lw.offB[j];
                 }
+                TRY(launch_lora_wgrad<T>(dY, ldy, z, lw.R, M, lw.n, 0, lw.r, nmod, lw.secN, oB, m.lora_scale, scratch, st));
+                TRY(launch_lora_wgrad<T>(x, ldx, dz, lw.R, M, lw.k, 1, lw.r, nmod, lw.secN, oA, 1.0f, scratch, st));
             }
         }
         if (!need_dx) return 0;

@@ -71,3 +71,80 @@ def test_shard_helpers_single_process():
             assert cover == list(range(n))
             assert sorted(i for r in range(w) for i in md.shard_indices(n, w, r)) == list(range(n))
     assert md.max_over_ranks(3.5) == 3.5 and md.sum_over_ranks(2.0) == 2.0
+
+
+def _dp_worker(rank, world, port, out):
+    """Data-parallel fine-tune exchange: per-rank micro-batch gradients of the adapters, one flat f32
+    bucket, SUM all-reduce, 1/world - must equal the single-process gradient of the concatenated batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "mri-diffusion-superresolution_amd"))
+    torch.set_num_threads(2)
+    from mrisr import dist as md
+    from oracle import unet as ou
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = ou.MNIST
+    up = ou.init_unet_params(cfg, seed=7)       # identical seeds for the weights on every rank
+    lora = ou.init_lora_params(up, rank=4, seed=8)
+    keys = sorted(lora)
+    g = torch.Generator().manual_seed(99)       # the GLOBAL batch; each rank takes its contiguous share
+    Bg = 2 * world
+    x = torch.randn((Bg, 1, 8, 8), generator=g)
+    ctx = torch.randn((Bg, 4, cfg.cross_attention_dim), generator=g)
+    tgt = torch.randn((Bg, 1, 8, 8), generator=g)
+    t = torch.randint(0, 1000, (Bg,), generator=g)
+
+    def flat_grad(sl):
+        lp = {k: v.clone().requires_grad_(True) for k, v in lora.items()}
+        pred = ou.unet_forward({**up, **lp}, cfg, x[sl], t[sl], ctx[sl])
+        torch.nn.functional.mse_loss(pred, tgt[sl]).backward()
+        return torch.cat([lp[k].grad.reshape(-1) for k in keys])
+
+    b, e = md.shard_range(Bg, world, rank)
+    bucket = flat_grad(slice(b, e)).contiguous()
+    w = md.all_reduce_sum_(bucket)
+    bucket /= w
+    norm = float(bucket.norm())
+    norms = [None] * world
+    dist.all_gather_object(norms, norm)
+    if rank == 0:
+        full = flat_grad(slice(0, Bg))
+        out.put({"world": w, "err": float((bucket - full).norm() / full.norm()), "norms": norms, "n": bucket.numel()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_large_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["world"] == 2 and res["n"] > 0
+    assert res["err"] < 1e-5                      # mean of per-rank means == mean over the global batch
+    assert res["norms"][0] == res["norms"][1]     # every rank clips with the same global norm: no second collective
+
+
+def test_all_reduce_is_identity_without_process_group():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mri-diffusion-superresolution_amd"))
+    from mrisr import dist as md
+    from mrisr.train import cosine_lr
+    v = torch.arange(5, dtype=torch.float32)
+    assert md.all_reduce_sum_(v) == 1 and torch.equal(v, torch.arange(5, dtype=torch.float32))
+    # diffusers get_cosine_schedule_with_warmup: linear warm-up, half cosine to 0
+    assert cosine_lr(0, 1e-4, 500, 10000) == 0.0
+    assert abs(cosine_lr(250, 1e-4, 500, 10000) - 5e-5) < 1e-12
+    assert abs(cosine_lr(500, 1e-4, 500, 10000) - 1e-4) < 1e-12
+    assert abs(cosine_lr(5250, 1e-4, 500, 10000) - 5e-5) < 1e-9
+    assert cosine_lr(10000, 1e-4, 500, 10000) < 1e-12

@@ -198,6 +198,10 @@ int mrisr_op_layernorm(const mrisr_tensor* x_rows, const float* gamma_dev, const
 int mrisr_op_attention(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, int heads, int flash,
                        mrisr_tensor* out, void* stream);
 
+/* gradients of mrisr_op_attention (bf16, flash path): dq [B,N,H*d], dk, dv [B,Nk,H*d] for an upstream dout [B,N,H*d] */
+int mrisr_op_attention_bwd(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, const mrisr_tensor* dout,
+                           int heads, mrisr_tensor* dq, mrisr_tensor* dk, mrisr_tensor* dv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,8 +170,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     bf16* ob = reinterpret_cast<bf16*>(a.out);
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-        const float inv = 1.0f / xor_sum(l_run[f]);
+        const float lsum = xor_sum(l_run[f]);
+        const float inv = 1.0f / lsum;
         const int q = q0 + f * 16 + fr;
+        if (a.lse && fg == 0 && q <= q_last)  // log2-domain log-sum-exp per query; +inf on the padding rows (P = 0 there)
+            a.lse[(size_t)bh * (q_last + 1) + q] = q < a.nq ? m_run[f] + __builtin_amdgcn_logf(lsum) : INFINITY;
         if (q < a.nq) {
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
@@ -212,6 +215,294 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     ATT_CASE(160, 9) ATT_CASE(160, 10)
 #undef ATT_CASE
     MRISR_REQUIRE(false, "attention: unsupported (padded head dim, head dim) combination");
+    return 0;
+}
+
+// ================================================================================================
+// backward.  Two passes over the same tile loop, P recomputed from the log-sum-exp instead of stored:
+//   MODE 0 (dQ):     a wave OWNS 16*QF queries (Q, dO rows in registers) and streams key tiles
+//                    S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - D) * scale,  dQ^T += K^T dS^T
+//   MODE 1 (dK, dV): a wave OWNS 16*QF keys (K, V rows in registers) and streams query tiles
+//                    S = Q K^T,  dP = dO V^T,  dS = P o (dP - D) * scale,  dK^T += Q^T dS,  dV^T += dO^T P
+// Same transposed trick as the forward: the lane that owns column `fr` of S holds exactly the k-slice the second MFMA
+// wants, so P / dS never leave registers; the streamed side comes through LDS both row-major (for S, dP) and
+// transposed (for the accumulating products).  No atomics: each output element has one owner.
+// ================================================================================================
+template <int DPAD, int DB, int KT, int QF, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
+    constexpr int KSTEPS = DPAD / 32;
+    constexpr int TT = KT / 16;            // 16-row blocks of the streamed tile
+    constexpr int SUBS = KT / 32;          // 32-deep steps of the accumulating products
+    constexpr int KP = DPAD * 2 + 16;      // row-major tile pitch (bytes)
+    constexpr int VP = KT * 2 + 16;        // transposed tile pitch (bytes)
+    constexpr int NCH = KT * DPAD / 8;     // 16-byte chunks per tile (either orientation)
+    constexpr int CPT = (NCH + 255) / 256;
+    constexpr int NT = MODE == 1 ? 2 : 1;  // transposed tiles
+    __shared__ __attribute__((aligned(16))) char y_lds[2][KT * KP];
+    __shared__ __attribute__((aligned(16))) char yt_lds[NT][DPAD * VP];
+    __shared__ float l_lds[KT], d_lds[KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y;
+    const int own0 = (blockIdx.x * 4 + wave) * (16 * QF);
+    const int own_pad = MODE == 0 ? a.npad : a.nkpad, own_valid = MODE == 0 ? a.nq : a.nk;
+    const int str_pad = MODE == 0 ? a.nkpad : a.npad, str_valid = MODE == 0 ? a.nk : a.nq;
+    const bf16* x1 = reinterpret_cast<const bf16*>(MODE == 0 ? a.q : a.k) + (size_t)bh * own_pad * DPAD;
+    const bf16* x2 = reinterpret_cast<const bf16*>(MODE == 0 ? a.doh : a.v) + (size_t)bh * own_pad * DPAD;
+    const bf16* y1 = reinterpret_cast<const bf16*>(MODE == 0 ? a.k : a.q) + (size_t)bh * str_pad * DPAD;
+    const bf16* y2 = reinterpret_cast<const bf16*>(MODE == 0 ? a.v : a.doh) + (size_t)bh * str_pad * DPAD;
+    const bf16* y1t = reinterpret_cast<const bf16*>(MODE == 0 ? a.kt : a.qt) + (size_t)bh * DPAD * str_pad;
+    const bf16* y2t = reinterpret_cast<const bf16*>(a.doht) + (size_t)bh * DPAD * str_pad;  // MODE 1 only
+    const float* lse = a.lse + (size_t)bh * a.npad;
+    const float* dsum = a.dsum + (size_t)bh * a.npad;
+    const float sl2 = a.scale * 1.4426950408889634f;
+
+    bf16x8 x1f[QF][KSTEPS], x2f[QF][KSTEPS];
+    float Lq[QF], Dq[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const int row = min(own0 + f * 16 + fr, own_pad - 1);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            x1f[f][kk] = *reinterpret_cast<const bf16x8*>(x1 + (size_t)row * DPAD + kk * 32 + fg * 8);
+            x2f[f][kk] = *reinterpret_cast<const bf16x8*>(x2 + (size_t)row * DPAD + kk * 32 + fg * 8);
+        }
+        Lq[f] = MODE == 0 ? lse[row] : 0.f;
+        Dq[f] = MODE == 0 ? dsum[row] : 0.f;
+    }
+    f32x4 acc1[QF][DB], acc2[QF][DB];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int d = 0; d < DB; ++d) acc1[f][d] = acc2[f][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 yreg[2][CPT], ytreg[NT][CPT];
+    float lreg = 0.f, dreg = 0.f;
+    auto fetch = [&](int s0) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = i * 256 + tid;
+            if (NCH % 256 == 0 || c < NCH) {
+                {
+                    const int row = c / (DPAD / 8), ch = c % (DPAD / 8);
+                    yreg[0][i] = *reinterpret_cast<const bf16x8*>(y1 + (size_t)(s0 + row) * DPAD + ch * 8);
+                    yreg[1][i] = *reinterpret_cast<const bf16x8*>(y2 + (size_t)(s0 + row) * DPAD + ch * 8);
+                }
+                {
+                    const int row = c / (KT / 8), ch = c % (KT / 8);
+                    ytreg[0][i] = *reinterpret_cast<const bf16x8*>(y1t + (size_t)row * str_pad + s0 + ch * 8);
+                    if (MODE == 1) ytreg[NT - 1][i] = *reinterpret_cast<const bf16x8*>(y2t + (size_t)row * str_pad + s0 + ch * 8);
+                }
+            }
+        }
+        if (MODE == 1 && tid < KT) {
+            lreg = lse[s0 + tid];
+            dreg = dsum[s0 + tid];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = i * 256 + tid;
+            if (NCH % 256 == 0 || c < NCH) {
+                {
+                    const int row = c / (DPAD / 8), ch = c % (DPAD / 8);
+                    *reinterpret_cast<bf16x8*>(y_lds[0] + row * KP + ch * 16) = yreg[0][i];
+                    *reinterpret_cast<bf16x8*>(y_lds[1] + row * KP + ch * 16) = yreg[1][i];
+                }
+                {
+                    const int row = c / (KT / 8), ch = c % (KT / 8);
+                    *reinterpret_cast<bf16x8*>(yt_lds[0] + row * VP + ch * 16) = ytreg[0][i];
+                    if (MODE == 1) *reinterpret_cast<bf16x8*>(yt_lds[NT - 1] + row * VP + ch * 16) = ytreg[NT - 1][i];
+                }
+            }
+        }
+        if (MODE == 1 && tid < KT) {
+            l_lds[tid] = lreg;
+            d_lds[tid] = dreg;
+        }
+    };
+
+    const int ntiles = (str_valid + KT - 1) / KT;
+    fetch(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int s0 = t * KT;
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (t + 1 < ntiles) fetch(s0 + KT);
+        f32x4 sv[QF][TT], dp[QF][TT];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) sv[f][tt] = dp[f][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(y_lds[0] + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
+                const bf16x8 f2 = *reinterpret_cast<const bf16x8*>(y_lds[1] + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    sv[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, x1f[f][kk], sv[f][tt], 0, 0, 0);
+                    dp[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2, x2f[f][kk], dp[f][tt], 0, 0, 0);
+                }
+            }
+        }
+        // lane holds streamed rows 16tt + 4fg + r of owner column fr
+        bf16x8 dsf[QF][SUBS], pf[QF][SUBS];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            f32x4 Lv, Dv;
+            if (MODE == 1) {
+                Lv = *reinterpret_cast<const f32x4*>(&l_lds[tt * 16 + fg * 4]);
+                Dv = *reinterpret_cast<const f32x4*>(&d_lds[tt * 16 + fg * 4]);
+            }
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float L = MODE == 0 ? Lq[f] : Lv[r];
+                    const float D = MODE == 0 ? Dq[f] : Dv[r];
+                    float p = __builtin_amdgcn_exp2f(fmaf(sv[f][tt][r], sl2, -L));
+                    if (MODE == 0 && s0 + tt * 16 + fg * 4 + r >= str_valid) p = 0.f;  // masked key
+                    const float ds = p * (dp[f][tt][r] - D) * a.scale;
+                    dsf[f][tt >> 1][(tt & 1) * 4 + r] = (bf16)ds;
+                    pf[f][tt >> 1][(tt & 1) * 4 + r] = (bf16)p;
+                }
+            }
+        }
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                typedef __attribute__((ext_vector_type(8))) short short8v;
+                {
+                    const char* row = yt_lds[0] + (d * 16 + fr) * VP + (sub * 32 + fg * 4) * 2;
+                    const short4v lo = *reinterpret_cast<const short4v*>(row);
+                    const short4v hi = *reinterpret_cast<const short4v*>(row + 32);
+                    const short8v packed = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 tf = __builtin_bit_cast(bf16x8, packed);
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) acc1[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, dsf[f][sub], acc1[f][d], 0, 0, 0);
+                }
+                if (MODE == 1) {
+                    const char* row = yt_lds[NT - 1] + (d * 16 + fr) * VP + (sub * 32 + fg * 4) * 2;
+                    const short4v lo = *reinterpret_cast<const short4v*>(row);
+                    const short4v hi = *reinterpret_cast<const short4v*>(row + 32);
+                    const short8v packed = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 tf = __builtin_bit_cast(bf16x8, packed);
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) acc2[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, pf[f][sub], acc2[f][d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- store: lane holds out^T[d = 16db + 4fg + r][owner = fr] ----
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int ld = MODE == 0 ? a.ldq : a.ldkv;
+    bf16* o1 = reinterpret_cast<bf16*>(MODE == 0 ? a.dq : a.dk);
+    bf16* o2 = reinterpret_cast<bf16*>(a.dv);
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const int own = own0 + f * 16 + fr;
+        if (own >= own_valid) continue;
+        const size_t base = ((size_t)b * own_valid + own) * ld + h * a.hd;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const int dd = d * 16 + fg * 4;
+            if (dd >= a.hd) continue;
+            const bf16x4 v1 = {(bf16)acc1[f][d][0], (bf16)acc1[f][d][1], (bf16)acc1[f][d][2], (bf16)acc1[f][d][3]};
+            *reinterpret_cast<bf16x4*>(o1 + base + dd) = v1;
+            if (MODE == 1) {
+                const bf16x4 v2 = {(bf16)acc2[f][d][0], (bf16)acc2[f][d][1], (bf16)acc2[f][d][2], (bf16)acc2[f][d][3]};
+                *reinterpret_cast<bf16x4*>(o2 + base + dd) = v2;
+            }
+        }
+    }
+}
+
+template <int DPAD, int DB>
+static int launch_bwd_dpad(const AttnBwdArgs& a, hipStream_t st) {
+    constexpr int KT = DPAD <= 96 ? 64 : 32;
+    const int BH = a.B * a.H;
+    bool big = false;
+    {
+        ProfScope ps("flash_attention_bwd_dq", 6.0 * BH * (double)a.nq * a.nk * a.hd, 2.0 * BH * (3.0 * a.nq * a.hd + 3.0 * a.nk * a.hd), st);
+        if constexpr (DPAD <= 64) {
+            if (a.nq >= 128) big = true;
+        }
+        if constexpr (DPAD <= 64) {
+            if (big) hipLaunchKernelGGL((attn_bwd_kernel<DPAD, DB, KT, 2, 0>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
+        }
+        if (!big)
+            hipLaunchKernelGGL((attn_bwd_kernel<DPAD, DB, KT, 1, 0>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
+    }
+    MRISR_CHECK_HIP(hipGetLastError());
+    if (a.dk) {
+        ProfScope ps("flash_attention_bwd_dkv", 8.0 * BH * (double)a.nq * a.nk * a.hd, 2.0 * BH * (4.0 * a.nq * a.hd + 4.0 * a.nk * a.hd), st);
+        bool big2 = false;
+        if constexpr (DPAD <= 64) {
+            if (a.nk >= 128) {
+                big2 = true;
+                hipLaunchKernelGGL((attn_bwd_kernel<DPAD, DB, KT, 2, 1>), dim3((a.nk + 127) / 128, BH), dim3(256), 0, st, a);
+            }
+        }
+        if (!big2)
+            hipLaunchKernelGGL((attn_bwd_kernel<DPAD, DB, KT, 1, 1>), dim3((a.nk + 63) / 64, BH), dim3(256), 0, st, a);
+        MRISR_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int launch_attention_bwd_bf16(const AttnBwdArgs& a, hipStream_t st) {
+    MRISR_REQUIRE(a.nkpad % 64 == 0 && a.npad % 64 == 0 && a.nk >= 1 && a.nk <= a.nkpad && a.nq >= 1 && a.nq <= a.npad, "attention bwd: padding");
+    MRISR_REQUIRE(a.hd % 4 == 0 && a.hd <= a.dpad && a.ldq % 4 == 0 && a.ldkv % 4 == 0, "attention bwd: head dim");
+    MRISR_REQUIRE(a.q && a.k && a.v && a.doh && a.kt && a.lse && a.dsum && a.dq, "attention bwd: operands");
+    MRISR_REQUIRE(!a.dk || (a.dv && a.qt && a.doht), "attention bwd: dK/dV operands");
+    const int db = (a.hd + 15) / 16;
+#define ATT_CASE(DP, DBV) if (a.dpad == DP && db == DBV) return launch_bwd_dpad<DP, DBV>(a, st);
+    ATT_CASE(32, 1) ATT_CASE(32, 2)
+    ATT_CASE(64, 3) ATT_CASE(64, 4)
+    ATT_CASE(96, 5) ATT_CASE(96, 6)
+    ATT_CASE(128, 7) ATT_CASE(128, 8)
+    ATT_CASE(160, 9) ATT_CASE(160, 10)
+#undef ATT_CASE
+    MRISR_REQUIRE(false, "attention bwd: unsupported (padded head dim, head dim) combination");
+    return 0;
+}
+
+// one thread per (b, token, head): its hd elements are contiguous in the token rows
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restrict__ dO, const bf16* __restrict__ O, bf16* __restrict__ doh,
+                                                            float* __restrict__ dsum, int B, int N, int H, int hd, int npad, int dpad) {
+    const long long total = (long long)B * N * H;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= total) return;
+    const int h = (int)(i % H);
+    const long long bq = i / H;
+    const int q = (int)(bq % N), b = (int)(bq / N);
+    const bf16* dr = dO + i * hd;
+    const bf16* orow = O + i * hd;
+    bf16* dst = doh + (((size_t)b * H + h) * npad + q) * dpad;
+    float s = 0.f;
+    for (int d = 0; d < hd; d += 4) {
+        const bf16x4 dv = *reinterpret_cast<const bf16x4*>(dr + d);
+        const bf16x4 ov = *reinterpret_cast<const bf16x4*>(orow + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += (float)dv[e] * (float)ov[e];
+        *reinterpret_cast<bf16x4*>(dst + d) = dv;
+    }
+    dsum[((size_t)b * H + h) * npad + q] = s;
+}
+int launch_attention_bwd_prep(const void* dO_rows, const void* O_rows, void* doh, float* dsum, int B, int N, int H, int hd, int npad,
+                              int dpad, hipStream_t st) {
+    MRISR_REQUIRE(hd % 4 == 0 && dpad % 4 == 0, "attention bwd prep: head dim");
+    const long long total = (long long)B * N * H;
+    ProfScope ps("flash_attention_bwd_prep", 0.0, 6.0 * total * hd, st);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bf16*>(dO_rows),
+                       reinterpret_cast<const bf16*>(O_rows), reinterpret_cast<bf16*>(doh), dsum, B, N, H, hd, npad, dpad);
+    MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -744,6 +744,60 @@ int mrisr_op_attention(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr
 
 }  // extern "C"
 
+// flash attention forward (with log-sum-exp) + backward on bf16 token rows: the kernels the fine-tuning step runs
+static int op_attention_bwd_bf16(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, const mrisr_tensor* dout, int H,
+                                 mrisr_tensor* dq, mrisr_tensor* dk, mrisr_tensor* dv, hipStream_t st) {
+    typedef bf16 T;
+    const int B = (int)q->shape[0], N = (int)q->shape[1], C = (int)q->shape[2], Nk = (int)k->shape[1];
+    const int hd = C / H, BH = B * H;
+    const int dpad = round_up(hd, 32), npad = round_up(N, 64), nkpad = round_up(Nk, 64);
+    const size_t qsz = (size_t)BH * npad * dpad * sizeof(T), ksz = (size_t)BH * nkpad * dpad * sizeof(T);
+    DevBuf qb, kb, vtb, vb, ktb, qtb, doh, doht, ob, lse, dsum;
+    TRY(qb.reserve(qsz, true)); TRY(kb.reserve(ksz, true)); TRY(vtb.reserve(ksz, true)); TRY(vb.reserve(ksz, true));
+    TRY(ktb.reserve(ksz, true)); TRY(qtb.reserve(qsz, true)); TRY(doh.reserve(qsz, true)); TRY(doht.reserve(qsz, true));
+    TRY(ob.reserve((size_t)B * N * C * sizeof(T), false));
+    TRY(lse.reserve((size_t)BH * npad * sizeof(float), true)); TRY(dsum.reserve((size_t)BH * npad * sizeof(float), true));
+    auto conv = [&](const mrisr_tensor* x, void* dst, int n, int np, int tr) {
+        hipLaunchKernelGGL(rows_to_heads_kernel<T>, dim3(1024), dim3(256), 0, st, static_cast<const T*>(x->data), static_cast<T*>(dst), B,
+                           n, H, hd, np, dpad, tr);
+    };
+    conv(q, qb.p, N, npad, 0);
+    conv(k, kb.p, Nk, nkpad, 0);
+    conv(v, vtb.p, Nk, nkpad, 1);
+    MRISR_CHECK_HIP(hipGetLastError());
+    const float scale = 1.0f / sqrtf((float)hd);
+    AttnArgs a;
+    a.q = qb.p; a.k = kb.p; a.vt = vtb.p; a.out = ob.p;
+    a.B = B; a.H = H; a.nq = N; a.nk = Nk; a.nkpad = nkpad; a.hd = hd; a.dpad = dpad; a.scale = scale;
+    a.lse = static_cast<float*>(lse.p);
+    TRY(launch_attention_bf16(a, st));
+    TRY(launch_attention_bwd_prep(dout->data, ob.p, doh.p, static_cast<float*>(dsum.p), B, N, H, hd, npad, dpad, st));
+    TRY(launch_transpose<T>(vtb.p, vb.p, dpad, nkpad, nkpad, dpad, (long long)dpad * nkpad, (long long)nkpad * dpad, BH, dpad, st));
+    TRY(launch_transpose<T>(kb.p, ktb.p, nkpad, dpad, dpad, nkpad, (long long)nkpad * dpad, (long long)dpad * nkpad, BH, nkpad, st));
+    TRY(launch_transpose<T>(qb.p, qtb.p, npad, dpad, dpad, npad, (long long)npad * dpad, (long long)dpad * npad, BH, npad, st));
+    TRY(launch_transpose<T>(doh.p, doht.p, npad, dpad, dpad, npad, (long long)npad * dpad, (long long)dpad * npad, BH, npad, st));
+    AttnBwdArgs g;
+    g.q = qb.p; g.k = kb.p; g.v = vb.p; g.doh = doh.p; g.qt = qtb.p; g.kt = ktb.p; g.doht = doht.p;
+    g.lse = static_cast<const float*>(lse.p); g.dsum = static_cast<const float*>(dsum.p);
+    g.dq = dq->data; g.ldq = C; g.dk = dk->data; g.dv = dv->data; g.ldkv = C;
+    g.B = B; g.H = H; g.nq = N; g.nk = Nk; g.npad = npad; g.nkpad = nkpad; g.hd = hd; g.dpad = dpad; g.scale = scale;
+    TRY(launch_attention_bwd_bf16(g, st));
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int mrisr_op_attention_bwd(const mrisr_tensor* q, const mrisr_tensor* k, const mrisr_tensor* v, const mrisr_tensor* dout,
+                                      int heads, mrisr_tensor* dq, mrisr_tensor* dk, mrisr_tensor* dv, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(q && k && v && dout && dq && dk && dv && q->ndim == 3 && q->dtype == MRISR_BF16 && k->dtype == MRISR_BF16 &&
+                      v->dtype == MRISR_BF16 && dout->dtype == MRISR_BF16 && dq->dtype == MRISR_BF16 && dk->dtype == MRISR_BF16 &&
+                      dv->dtype == MRISR_BF16,
+                  "attention backward: bf16 [B,N,C] tensors");
+    MRISR_REQUIRE(heads >= 1 && q->shape[2] % heads == 0 && (q->shape[2] / heads) % 4 == 0, "head dim must be a multiple of 4");
+    return op_attention_bwd_bf16(q, k, v, dout, heads, dq, dk, dv, (hipStream_t)stream);
+    API_END
+}
+
 // =================================================================================================
 // GEMM micro-benchmark (tools/gemm_sweep.py): times one implicit-GEMM shape with a forced tile / split-K on
 // pseudo-random operands (zero-filled operands would flatter the clock; guide rule 25).

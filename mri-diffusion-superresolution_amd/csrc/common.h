@@ -193,8 +193,34 @@ struct AttnArgs {
     void* out = nullptr;
     int B = 0, H = 0, nq = 0, nk = 0, nkpad = 0, hd = 0, dpad = 0;
     float scale = 1.0f;
+    float* lse = nullptr;  // optional [B*H][npad]: log2-domain log-sum-exp of scale*s (training keeps it for the backward)
 };
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);
+// flash attention backward (attn.hip): P is recomputed from Q, K and the forward's log-sum-exp, never materialised.
+//   head-major operands, pads zero:  q, doh [B*H][npad][dpad];  k, v [B*H][nkpad][dpad];  their transposes qt, doht
+//   [B*H][dpad][npad], kt [B*H][dpad][nkpad];  lse, dsum [B*H][npad] (dsum = rowsum(dO o O), 0 on pads).
+//   Outputs as token rows (head h -> columns h*hd..): dq [B][nq][ldq]; dk, dv [B][nk][ldkv] (both may be null).
+struct AttnBwdArgs {
+    const void* q = nullptr;
+    const void* k = nullptr;
+    const void* v = nullptr;
+    const void* doh = nullptr;
+    const void* qt = nullptr;
+    const void* kt = nullptr;
+    const void* doht = nullptr;
+    const float* lse = nullptr;
+    const float* dsum = nullptr;
+    void* dq = nullptr;
+    void* dk = nullptr;
+    void* dv = nullptr;
+    int ldq = 0, ldkv = 0;
+    int B = 0, H = 0, nq = 0, nk = 0, npad = 0, nkpad = 0, hd = 0, dpad = 0;
+    float scale = 1.0f;
+};
+int launch_attention_bwd_bf16(const AttnBwdArgs& a, hipStream_t st);
+// dO / O token rows [B][N][H*hd] -> doh head-major [B*H][npad][dpad] (valid region only) and dsum[b*H+h][q] = sum_d dO*O
+int launch_attention_bwd_prep(const void* dO_rows, const void* O_rows, void* doh, float* dsum, int B, int N, int H, int hd, int npad,
+                              int dpad, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // small kernels (misc.hip)

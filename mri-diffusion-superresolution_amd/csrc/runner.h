@@ -157,7 +157,7 @@ struct Runner {
     int attention(const HeadBuf& hb, const void* k, const void* vt, int nk, int nkpad, void* out_rows) {
         const int BH = hb.B * hb.H;
         const float scale = 1.0f / sqrtf((float)hb.hd);
-        if (m.cfg.flash_attention && sizeof(T) == 2 && !m.keep) {
+        if (m.cfg.flash_attention && sizeof(T) == 2) {
             AttnArgs a;
             a.q = hb.q; a.k = k; a.vt = vt; a.out = out_rows;
             a.B = hb.B; a.H = hb.H; a.nq = hb.N; a.nk = nk; a.nkpad = nkpad; a.hd = hb.hd; a.dpad = hb.dpad;

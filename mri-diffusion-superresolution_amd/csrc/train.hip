@@ -296,14 +296,29 @@ struct Trainer : Runner<T> {
         const void* q = nullptr;   // [B*H][npad][dpad]
         const void* k = nullptr;   // [B*H][nkpad][dpad]
         const void* vt = nullptr;  // [B*H][dpad][nkpad]
-        const void* P = nullptr;   // [B*H][N][nkpad] softmax probabilities (T)
+        const void* P = nullptr;   // [B*H][N][nkpad] softmax probabilities (T): materialised path only
+        const float* lse = nullptr;  // [B*H][npad] log-sum-exp: flash path only
+        const void* out = nullptr; // attention output rows [M][C] (flash backward: D = rowsum(dO o O))
         int nk = 0, nkpad = 0;
     };
+    bool flash() const { return sizeof(T) == 2 && m.cfg.flash_attention; }
 
     // materialised attention that keeps P for the backward
     int attention_t(const HeadBuf& hb, AttnRec* a, void* out_rows) {
         const int BH = hb.B * hb.H;
         const float scale = 1.0f / sqrtf((float)hb.hd);
+        a->out = out_rows;
+        if (flash()) {
+            float* lse = static_cast<float*>(alloc((size_t)BH * hb.npad * sizeof(float)));
+            if (!lse) return 7;
+            a->lse = lse;
+            AttnArgs fa;
+            fa.q = a->q; fa.k = a->k; fa.vt = a->vt; fa.out = out_rows;
+            fa.B = hb.B; fa.H = hb.H; fa.nq = hb.N; fa.nk = a->nk; fa.nkpad = a->nkpad; fa.hd = hb.hd; fa.dpad = hb.dpad;
+            fa.scale = scale; fa.lse = lse;
+            if (dry) return 0;
+            return launch_attention_bf16(fa, st);
+        }
         const size_t cnt = (size_t)BH * hb.N * a->nkpad;
         float* S;
         void* P;
@@ -342,6 +357,31 @@ struct Trainer : Runner<T> {
         const int BH = hb.B * hb.H, N = hb.N, npad = hb.npad, dpad = hb.dpad, nk = a.nk, nkpad = a.nkpad;
         const float scale = 1.0f / sqrtf((float)hb.hd);
         const size_t qsz = (size_t)BH * npad * dpad, ksz = (size_t)BH * nkpad * dpad, psz = (size_t)BH * N * nkpad;
+        if (flash()) {
+            // P recomputed from the log-sum-exp inside the kernels; only [tokens x head dim] operands are staged
+            void* doh = alloc(qsz * sizeof(T));
+            float* dsum = static_cast<float*>(alloc((size_t)BH * npad * sizeof(float)));
+            void* V = alloc(ksz * sizeof(T));
+            void* Kt = alloc(ksz * sizeof(T));
+            void* Qt = dk ? alloc(qsz * sizeof(T)) : nullptr;
+            void* doht = dk ? alloc(qsz * sizeof(T)) : nullptr;
+            if (!doh || !dsum || !V || !Kt || (dk && (!Qt || !doht))) return 7;
+            TRY(zero(doh, qsz * sizeof(T)));
+            TRY(zero(dsum, (size_t)BH * npad * sizeof(float)));
+            if (dry) return 0;
+            TRY(launch_attention_bwd_prep(dO_rows, a.out, doh, dsum, hb.B, N, hb.H, hb.hd, npad, dpad, st));
+            TRY(launch_transpose<T>(a.vt, V, dpad, nkpad, nkpad, dpad, (long long)dpad * nkpad, (long long)nkpad * dpad, BH, dpad, st));
+            TRY(launch_transpose<T>(a.k, Kt, nkpad, dpad, dpad, nkpad, (long long)nkpad * dpad, (long long)dpad * nkpad, BH, nkpad, st));
+            if (dk) {
+                TRY(launch_transpose<T>(a.q, Qt, npad, dpad, dpad, npad, (long long)npad * dpad, (long long)dpad * npad, BH, npad, st));
+                TRY(launch_transpose<T>(doh, doht, npad, dpad, dpad, npad, (long long)npad * dpad, (long long)dpad * npad, BH, npad, st));
+            }
+            AttnBwdArgs g;
+            g.q = a.q; g.k = a.k; g.v = V; g.doh = doh; g.qt = Qt; g.kt = Kt; g.doht = doht; g.lse = a.lse; g.dsum = dsum;
+            g.dq = dq; g.ldq = ldq; g.dk = dk; g.dv = dv; g.ldkv = ldkv;
+            g.B = hb.B; g.H = hb.H; g.nq = N; g.nk = nk; g.npad = npad; g.nkpad = nkpad; g.hd = hb.hd; g.dpad = dpad; g.scale = scale;
+            return launch_attention_bwd_bf16(g, st);
+        }
         T* dOh = static_cast<T*>(alloc(qsz * sizeof(T)));
         T* V = static_cast<T*>(alloc(ksz * sizeof(T)));
         float* dP = static_cast<float*>(alloc(psz * sizeof(float)));

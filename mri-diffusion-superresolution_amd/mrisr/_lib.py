@@ -56,6 +56,7 @@ EXPORTS = [
     "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_optim_sumsq", "mrisr_optim_adamw",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
     "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
+    "mrisr_op_attention_bwd",
 ]
 
 

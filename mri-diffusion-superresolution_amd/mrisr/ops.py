@@ -92,3 +92,14 @@ def attention(q, k, v, heads, flash=True):
     L.check(L.lib().mrisr_op_attention(C.byref(tq), C.byref(tk), C.byref(tv), heads, 1 if flash else 0, C.byref(to),
                                        L.stream_ptr()))
     return out
+
+
+def attention_backward(q, k, v, dout, heads):
+    """Gradients (dq, dk, dv) of ``attention`` w.r.t. its bf16 inputs for an upstream ``dout`` [B,N,C]: the flash
+    forward (keeping the log-sum-exp) followed by the two backward kernels the fine-tuning step uses."""
+    q, k, v, dout = (t.contiguous() for t in (q, k, v, dout))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ts = [L.as_tensor(t) for t in (q, k, v, dout, dq, dk, dv)]
+    L.check(L.lib().mrisr_op_attention_bwd(C.byref(ts[0]), C.byref(ts[1]), C.byref(ts[2]), C.byref(ts[3]), heads,
+                                           C.byref(ts[4]), C.byref(ts[5]), C.byref(ts[6]), L.stream_ptr()))
+    return dq, dk, dv

@@ -137,6 +137,24 @@ def test_attention_flash_online_softmax_rescale_branch():
     assert rel(y, ref) < 2e-2
 
 
+@pytest.mark.parametrize("B,N,Nk,C,H", [(2, 256, 256, 320, 8), (1, 1024, 1024, 320, 8), (2, 64, 64, 1280, 8),
+                                        (2, 16, 16, 1280, 8), (2, 256, 77, 640, 8), (1, 200, 77, 64, 8),
+                                        (1, 64, 64, 256, 8), (1, 100, 130, 1024, 8)])
+def test_attention_backward_matches_autograd(B, N, Nk, C, H):
+    """Flash backward (P recomputed from the log-sum-exp, dQ pass + dK/dV pass) against torch autograd of the f32 SDPA on
+    the same bf16-rounded inputs; ragged query / key counts, every padded head dim the SD-1.5 levels use."""
+    from mrisr import ops
+    q, k, v = _rnd((B, N, C), "bf16", 41), _rnd((B, Nk, C), "bf16", 42), _rnd((B, Nk, C), "bf16", 43)
+    do = _rnd((B, N, C), "bf16", 44)
+    with torch.enable_grad():
+        qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+        _sdpa(qf, kf, vf, H).backward(do.float())
+    dq, dk, dv = ops.attention_backward(q.cuda(), k.cuda(), v.cuda(), do.cuda(), H)
+    assert rel(dq, qf.grad) < 2e-2, ("dq", rel(dq, qf.grad))
+    assert rel(dk, kf.grad) < 2e-2, ("dk", rel(dk, kf.grad))
+    assert rel(dv, vf.grad) < 2e-2, ("dv", rel(dv, vf.grad))
+
+
 @pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 25, 26, 27, 28, 29, 30, 31])
 @pytest.mark.parametrize("M,N,K,splitk", [(512, 320, 256, 1), (1000, 640, 384, 1), (256, 1280, 2048, 4), (300, 68, 192, 1),
                                           (4096, 960, 384, 1), (130, 320, 64, 1)])

@@ -473,34 +473,40 @@ int launch_attention_bwd_bf16(const AttnBwdArgs& a, hipStream_t st) {
     return 0;
 }
 
-// one thread per (b, token, head): its hd elements are contiguous in the token rows
+// one wave per token row: lanes sweep the row's 8-byte chunks (coalesced), per-head partial dot products fold through LDS
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16* __restrict__ dO, const bf16* __restrict__ O, bf16* __restrict__ doh,
                                                             float* __restrict__ dsum, int B, int N, int H, int hd, int npad, int dpad) {
-    const long long total = (long long)B * N * H;
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
-    if (i >= total) return;
-    const int h = (int)(i % H);
-    const long long bq = i / H;
-    const int q = (int)(bq % N), b = (int)(bq / N);
-    const bf16* dr = dO + i * hd;
-    const bf16* orow = O + i * hd;
-    bf16* dst = doh + (((size_t)b * H + h) * npad + q) * dpad;
-    float s = 0.f;
-    for (int d = 0; d < hd; d += 4) {
-        const bf16x4 dv = *reinterpret_cast<const bf16x4*>(dr + d);
-        const bf16x4 ov = *reinterpret_cast<const bf16x4*>(orow + d);
+    __shared__ float hs[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = blockIdx.x * 4ll + wave;  // b * N + q
+    const bool live = row < (long long)B * N;
+    if (lane < H) hs[wave][lane] = 0.f;
+    __syncthreads();
+    const int q = live ? (int)(row % N) : 0, b = live ? (int)(row / N) : 0;
+    if (live) {
+        const int C = H * hd;
+        const bf16* dr = dO + row * C;
+        const bf16* orow = O + row * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const bf16x4 dv = *reinterpret_cast<const bf16x4*>(dr + c);
+            const bf16x4 ov = *reinterpret_cast<const bf16x4*>(orow + c);
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += (float)dv[e] * (float)ov[e];
-        *reinterpret_cast<bf16x4*>(dst + d) = dv;
+            for (int e = 0; e < 4; ++e) s += (float)dv[e] * (float)ov[e];
+            const int h = c / hd, dd = c - h * hd;
+            *reinterpret_cast<bf16x4*>(doh + (((size_t)b * H + h) * npad + q) * dpad + dd) = dv;
+            atomicAdd(&hs[wave][h], s);
+        }
     }
-    dsum[((size_t)b * H + h) * npad + q] = s;
+    __syncthreads();
+    if (live && lane < H) dsum[((size_t)b * H + lane) * npad + q] = hs[wave][lane];
 }
 int launch_attention_bwd_prep(const void* dO_rows, const void* O_rows, void* doh, float* dsum, int B, int N, int H, int hd, int npad,
                               int dpad, hipStream_t st) {
-    MRISR_REQUIRE(hd % 4 == 0 && dpad % 4 == 0, "attention bwd prep: head dim");
-    const long long total = (long long)B * N * H;
-    ProfScope ps("flash_attention_bwd_prep", 0.0, 6.0 * total * hd, st);
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bf16*>(dO_rows),
+    MRISR_REQUIRE(hd % 4 == 0 && dpad % 4 == 0 && H <= 64, "attention bwd prep: head dim / head count");
+    const long long rows = (long long)B * N;
+    ProfScope ps("flash_attention_bwd_prep", 0.0, 6.0 * rows * H * hd, st);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const bf16*>(dO_rows),
                        reinterpret_cast<const bf16*>(O_rows), reinterpret_cast<bf16*>(doh), dsum, B, N, H, hd, npad, dpad);
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;

@@ -60,12 +60,66 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
     }
 }
 
+// Several rows (per-sample timesteps: rows = batch): the same product on the matrix cores.  A wave owns 16 output
+// columns; per 32-deep k step it streams one W fragment (16 n x 32 k, 16 B per lane) and builds NB x fragments
+// (16 rows x 32 k) from the tiny L2-resident f32 input, applying SiLU and rounding to bf16 on the way.
+template <int NB>
+__global__ __launch_bounds__(256) void gemv_rows_mfma_kernel(const float* __restrict__ x, int ldx, const bf16* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int ldy, int rows,
+                                                             int N, int K, int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (n0 >= N) return;
+    const bf16* wr = w + (size_t)min(n0 + fr, N - 1) * K + fg * 8;
+    const float* xr[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xr[b] = x + (size_t)min(b * 16 + fr, rows - 1) * ldx + fg * 8;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k += 32) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + k);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xr[b] + k);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(xr[b] + k + 4);
+            bf16x8 xf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xf[e] = (bf16)(silu_in ? silu_f(lo[e]) : lo[e]);
+                xf[4 + e] = (bf16)(silu_in ? silu_f(hi[e]) : hi[e]);
+            }
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[b], 0, 0, 0);  // D[n = 4fg + r][row = fr]
+        }
+    }
+    const int n = n0 + fg * 4;
+    if (n >= N) return;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int row = b * 16 + fr;
+        if (row < rows) *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + n) = acc[b] + bv;
+    }
+}
+
 template <typename T>
 int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, float* y, int ldy, int rows, int N,
                      int K, int silu_in, hipStream_t st) {
     MRISR_REQUIRE(K % (16 / (int)sizeof(T)) == 0, "gemv K alignment");
     const dim3 grid((N + 3) / 4);
     ProfScope ps("time_embed_gemv", 2.0 * rows * (double)N * K, (double)N * K * sizeof(T), st);
+    if (sizeof(T) == 2 && rows > 1 && rows <= 64 && K % 32 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) {
+        const dim3 g2((N + 63) / 64);
+        const bf16* wp = reinterpret_cast<const bf16*>(w);
+        if (rows <= 16) hipLaunchKernelGGL((gemv_rows_mfma_kernel<1>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
+        else if (rows <= 32) hipLaunchKernelGGL((gemv_rows_mfma_kernel<2>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
+        else if (rows <= 48) hipLaunchKernelGGL((gemv_rows_mfma_kernel<3>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
+        else hipLaunchKernelGGL((gemv_rows_mfma_kernel<4>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
+        MRISR_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (rows <= 1)
         hipLaunchKernelGGL((gemv_rows_kernel<T, 1>), grid, dim3(256), 0, st, x, ldx, reinterpret_cast<const T*>(w), bias,
                            y, ldy, rows, N, K, silu_in);

@@ -168,3 +168,32 @@ def test_train_errors(tiny):
     x, t, ctx, tgt = make_batch(cfg, 1, 8, 50, L=16)
     with pytest.raises(mrisr.MrisrError, match="target"):
         tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt[:, :2].contiguous().cuda())
+
+
+def test_step_through_rccl_process_group(tiny):
+    """The exchange step on the real backend: a (single-rank) RCCL group - the flat gradient bucket is all-reduced on the
+    device between backward and the optimiser, and the result equals the group-less step."""
+    import socket
+    import torch.distributed as dist
+    import mrisr
+    cfg, up, lora = tiny
+    x, t, ctx, tgt = make_batch(cfg, 2, 8, 60, L=16)
+
+    def one_step():
+        net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+        net.load_state_dict({**up, **lora})
+        tr = mrisr.LoRATrainer(net, lr=1e-3)
+        tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+        return tr.theta.clone()
+
+    ref = one_step()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        got = one_step()
+    finally:
+        dist.destroy_process_group()
+    assert rel(got, ref) < 1e-5

@@ -104,6 +104,11 @@ struct GemmArgs {
     const float* lora_z = nullptr;
     const float* lora_b = nullptr;
     int lora_r = 0, lora_zld = 0, lora_secN = 1;
+    // bf16 buffer-addressed kernels, un-split plain GEMMs: compute z inside the GEMM instead (lora_z unused):
+    //   lora_a = A [lora_R <= 16][K] (compute dtype); lora_zout (optional): z is also written there, f32 [M][lora_R]
+    const void* lora_a = nullptr;
+    int lora_R = 0;
+    float* lora_zout = nullptr;
 };
 
 template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);

@@ -64,7 +64,7 @@ __device__ __forceinline__ void load4<bf16>(const bf16* p, float* v) {
 
 // v: accumulated values (already summed over K) for columns n0..n0+3 (GEGLU: u values; gate in vg).
 template <typename T>
-__device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg) {
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg, const float* zl = nullptr) {
     const float alpha = g.alpha;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.act == ACT_GEGLU) {
@@ -85,9 +85,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
     if (g.bias) load4<float>(g.bias + n0, b4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = v[r] * alpha + b4[r];
-    if (g.lora_z) {
-        // fused LoRA: the rank-r update of these 4 columns (r is tiny: 4 FMAs per output for rank 4)
-        const float* zr = g.lora_z + (size_t)m * g.lora_zld + (n0 / g.lora_secN) * g.lora_r;
+    if (g.lora_z || zl) {
+        // fused LoRA: the rank-r update of these 4 columns (r is tiny: 4 FMAs per output for rank 4).  zl: this row's
+        // down-projection computed by the same workgroup (LDS); otherwise z comes from launch_lora_down (global)
+        const float* zr = (zl ? zl : g.lora_z + (size_t)m * g.lora_zld) + (n0 / g.lora_secN) * g.lora_r;
         const float* lb = g.lora_b + (size_t)n0 * g.lora_r;
         if (g.lora_r == 4) {  // the common rank: five 16-byte loads instead of twenty scalar ones
             float z4[4];
@@ -431,7 +432,10 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 // other's load latency.  NSTAGE > 2: an LDS ring with NSTAGE-1 tiles of LDS-DMA in flight behind a counted
 // `s_waitcnt vmcnt(N)` and a raw `s_barrier` - for shapes with too few tiles to give every CU two workgroups
 // (small M / deep K), where the 2-stage loop is bound by one exposed load latency per K tile.
-template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+// LORA: the adapter's down-projection z = x A^T (R <= 16 rows of A ride along as 16 extra "weight" rows of every K
+// tile; one wave column accumulates z for its rows on the matrix cores) is computed by the workgroup itself and handed
+// to the epilogue through LDS - no separate pass over x, no z round trip through HBM.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool LORA>
 __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
     // Only the 2-stage form is instantiated: it synchronises with vmcnt(0), which is correct however out-of-range
     // (zero-fill) LDS-DMA instructions retire.  The counted-vmcnt ring below is kept for reference but must not be used
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
     constexpr int A_IT = BM / 32, W_IT = BN / 32;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MF = WTM / 16, NF = WTN / 16;
-    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int STAGE = (BM + BN) * 128 + (LORA ? 16 * 128 : 0);
     static_assert(WGM * WGN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -510,6 +514,14 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
         }
     }
     const int acb = pch * 16;  // physical chunk byte offset is applied through `c` below for conv rows
+    // adapter rows (LORA): waves 0 and 1 each bring 8 of the 16 rows of every K tile
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(LORA ? g.lora_a : (const void*)wp, LORA ? (unsigned)((long long)g.lora_R * g.K * 2) : 0u);
+    unsigned lvo = BL_OOB;
+    if (LORA && wave < 2) {
+        const int row = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        if (row < g.lora_R) lvo = (unsigned)(((size_t)row * g.K + c * 8) * 2);
+    }
 
     const int nkt = g.K / BK;
     const int per = (nkt + g.splitk - 1) / g.splitk;
@@ -539,6 +551,7 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, wvo[it], k0b);
+        if (LORA && wave < 2) bl16(rl, sb + (BM + BN) * 128 + wave * 64 * 16, lvo, k0b);
         if (!g.conv) {
             const bool second = kt * BK >= g.c0;
             if (!second) {
@@ -588,6 +601,10 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
 
     const int wm0 = (wave / WGN) * WTM, wn0 = (wave % WGN) * WTN;
     const int fr = lane & 15, fg = lane >> 4;
+    const bool zwave = LORA && (wave % WGN) == 0;  // the wave column that also accumulates z for its rows
+    f32x4 zacc[MF];
+#pragma unroll
+    for (int j = 0; j < MF; ++j) zacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE;
@@ -604,6 +621,11 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            if (LORA && zwave) {
+                const bf16x8 lf = *reinterpret_cast<const bf16x8*>(sw + (BN + fr) * 128 + phys);
+#pragma unroll
+                for (int j = 0; j < MF; ++j) zacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[j], zacc[j], 0, 0, 0);
+            }
         }
     };
 
@@ -621,6 +643,19 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
         }
     }
 
+    float* zlds = reinterpret_cast<float*>(smem);  // [BM][16] f32: z rows of this tile (the stages are drained)
+    if (LORA) {
+        if (zwave) {
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int ml = wm0 + j * 16 + fr;
+                *reinterpret_cast<f32x4*>(zlds + ml * 16 + fg * 4) = zacc[j];  // z[q = 4fg + r][m = fr]
+                if (g.lora_zout && tn == 0 && m0 + ml < g.M && fg * 4 < g.lora_R)
+                    *reinterpret_cast<f32x4*>(g.lora_zout + (size_t)(m0 + ml) * g.lora_R + fg * 4) = zacc[j];
+            }
+        }
+        __syncthreads();
+    }
     if (g.splitk > 1) {
         float* part = g.partial + ((size_t)z * g.splitk + split) * (size_t)g.M * g.N;
 #pragma unroll
@@ -661,7 +696,7 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, z, m, n, v, nullptr);
+                epilogue4<T>(g, z, m, n, v, nullptr, LORA ? zlds + (m - m0) * 16 : nullptr);
             }
         }
 }
@@ -734,9 +769,11 @@ extern "C" void mrisr_debug_force_tile(int t) { g_force_tile = t; }
 template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 static int prepare_bl() {
     constexpr int smem = NSTAGE * (BM + BN) * 128;
+    constexpr int smem_l = NSTAGE * ((BM + BN) * 128 + 16 * 128);
     static bool done = false;
     if (!done) {
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_l));
         done = true;
     }
     return 0;
@@ -744,6 +781,7 @@ static int prepare_bl() {
 template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 static int launch_bl(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = NSTAGE * (BM + BN) * 128;
+    constexpr int smem_l = NSTAGE * ((BM + BN) * 128 + 16 * 128);
     if (prepare_bl<BM, BN, WGM, WGN, NSTAGE>()) return 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     dim3 grid(ntn * ntm, g.splitk, g.batch);
@@ -764,7 +802,13 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
         }
     }
     ProfScope ps(prof_intern(pname), fl, by, st);
-    hipLaunchKernelGGL((gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE>), grid, dim3(256), smem, st, g);
+    if (g.lora_a) {
+        MRISR_REQUIRE(g.splitk == 1 && !g.conv && g.c1 == 0 && g.lora_R >= 1 && g.lora_R <= 16 && g.lora_b && g.act != ACT_GEGLU,
+                      "in-kernel LoRA down-projection: plain un-split GEMM, R <= 16");
+        hipLaunchKernelGGL((gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE, true>), grid, dim3(256), smem_l, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_bl_kernel<BM, BN, WGM, WGN, NSTAGE, false>), grid, dim3(256), smem, st, g);
+    }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -918,6 +962,8 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     g.out = g_ts.p[3]; g.ldo = g.act == ACT_GEGLU ? g.N / 2 : g.N;
     if (g.resid) { g.resid = g_ts.p[3]; g.ldr = g.ldo; }
     g.lora_z = nullptr;  // the rank-r epilogue term is negligible for ranking the candidates
+    g.lora_a = nullptr;
+    g.lora_zout = nullptr;
     const int nkt = g.K / 64;
     const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     double best = 1e30;

@@ -3,6 +3,7 @@
 #pragma once
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "model.h"
 
@@ -15,6 +16,13 @@ namespace mrisr {
         if (_rc) return _rc;   \
     } while (0)
 #endif
+
+// MRISR_LORA_INKERNEL=0 restores the separate down-projection pass (A/B measurements)
+inline bool lora_in_kernel() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRISR_LORA_INKERNEL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 
 // ================================================================================================
 // forward
@@ -93,20 +101,35 @@ struct Runner {
         GemmArgs g = custom ? *custom : GemmArgs();
         const size_t mk = m.arena.mark();
         g.a0 = x; g.c0 = lw.k; g.lda0 = lda;
-        if (lw.R) {
-            // LoRA: z = x A^T (f32 [M][R], one bandwidth-bound pass over x); the rank-r up-projection (alpha/r) B z is
-            // accumulated in the projection GEMM's epilogue
-            float* z = static_cast<float*>(alloc((size_t)M * lw.R * sizeof(float)));
-            if (!z) return 7;
-            if (!dry) TRY(launch_lora_down<T>(x, lda, lw.loraA, z, M, lw.k, lw.R, st));
-            g.lora_z = z; g.lora_zld = lw.R; g.lora_b = lw.loraB; g.lora_r = lw.r; g.lora_secN = lw.secN;
-            if (z_out) *z_out = z;
-        }
         g.w = lw.w; g.M = M; g.N = lw.n; g.K = lw.k;
         g.alg_flops = 2.0 * M * (double)lw.n * (lw.k + lw.r);
         g.bias = lw.b; g.act = act; g.resid = resid; g.ldr = ldr;
         if (g.out_mode != OUT_HEADS) { g.out = out; g.ldo = ldo; }
-        TRY(run_gemm(g));
+        if (!lw.R) {
+            TRY(run_gemm(g));
+            if (!m.keep) m.arena.release(mk);
+            return 0;
+        }
+        // LoRA: the rank-r up-projection (alpha/r) B z is accumulated in the projection GEMM's epilogue.  z = x A^T is
+        // computed inside the same kernel (bf16 buffer-addressed tiles, un-split); otherwise by one bandwidth-bound
+        // pass over x (launch_lora_down) that hands z over through HBM.
+        g.lora_zld = lw.R; g.lora_b = lw.loraB; g.lora_r = lw.r; g.lora_secN = lw.secN;
+        TRY(gemm_choose(g, sizeof(T) == 2));
+        float* z = static_cast<float*>(alloc((size_t)M * lw.R * sizeof(float)));
+        if (!z) return 7;
+        if (z_out) *z_out = z;
+        const bool in_kernel = sizeof(T) == 2 && lw.R <= 16 && g.splitk == 1 && g.tile >= 14 && lora_in_kernel();
+        if (in_kernel) {
+            g.lora_a = lw.loraA; g.lora_R = lw.R; g.lora_zout = z_out ? z : nullptr;
+        } else {
+            if (!dry) TRY(launch_lora_down<T>(x, lda, lw.loraA, z, M, lw.k, lw.R, st));
+            g.lora_z = z;
+        }
+        if (g.splitk > 1) {
+            g.partial = static_cast<float*>(alloc((size_t)g.splitk * g.batch * g.M * g.N * sizeof(float)));
+            if (!g.partial) return 7;
+        }
+        if (!dry) TRY(launch_gemm<T>(g, st));
         if (!m.keep) m.arena.release(mk);
         return 0;
     }

@@ -701,6 +701,193 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
         }
 }
 
+// =================================================================================================
+// 3x3 convolution with an LDS-staged halo ("halo"): stride 1, no up-sampling, image width a multiple of 16 and a
+// whole number of M tiles per image.  An M tile is BM/W consecutive image rows; for each 64-channel chunk of the input
+// the (BM/W + 2) x (W + 2) pixel neighbourhood is brought into LDS ONCE (zero padding = out-of-range DMA) and all nine
+// taps read their shifted A fragments from it, so the LDS fill per (tap, chunk) phase is only the weight tile:
+// BN x 128 B instead of (BM + BN) x 128 B.  The plain kernel above is capped by that fill bandwidth.
+// Weights stay double buffered per tap; the K order (ky, kx, cin) of the packed filter bank is unchanged.
+// =================================================================================================
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void gemm_halo_kernel(const GemmArgs g) {
+    typedef bf16 T;
+    constexpr int BK = 64;
+    constexpr int W_IT = BN / 32;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int MF = WTM / 16, NF = WTN / 16;
+    constexpr int WSTAGE = BN * 128;
+    constexpr int PIT_MAX = (BM >= 256 ? 13 : (BM >= 128 ? 9 : 6));  // 16-byte transfers per thread for the largest supported patch
+    static_assert(WGM * WGN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.y;
+    const int Wd = g.Win, Hd = g.Hin;
+    const int TH = BM / Wd, PW = Wd + 2;
+    const int npix = (TH + 2) * PW;
+    const int pit = (npix * 8 + 255) / 256;
+    char* patch = smem;
+    char* wbase = smem + pit * 4096;  // whole DMA rounds: lanes past the last patch pixel still write (zeros)
+
+    const int ntn = (g.N + BN - 1) / BN;
+    const int ntm = g.M / BM;
+    const int nblk = ntn * ntm;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = logical % ntn, tm = logical / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int img = m0 / (Hd * Wd);
+    const int y0 = (m0 - img * Hd * Wd) / Wd;  // first output row of the tile inside its image
+
+    const T* a0p = reinterpret_cast<const T*>(g.a0);
+    const T* a1p = reinterpret_cast<const T*>(g.a1);
+    const T* wp = reinterpret_cast<const T*>(g.w);
+    const long long a_rows = (long long)g.B * Hd * Wd;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)min((long long)g.N * g.K * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(a0p, (unsigned)min(a_rows * g.lda0 * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(a1p ? (const void*)a1p : (const void*)a0p,
+                                                 a1p ? (unsigned)min(a_rows * g.lda1 * 2, 0x7FFFFFFFll) : 0u);
+
+    // weight rows: as in the plain kernel
+    const int lrow = tid >> 3, pch = tid & 7;
+    unsigned wvo[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int row = it * 32 + lrow;
+        const int n = n0 + row;
+        const int c = pch ^ (row & 7);
+        wvo[it] = n < g.N ? (unsigned)(((size_t)n * g.K + c * 8) * 2) : BL_OOB;
+    }
+    // patch transfers: transfer t = it*256 + tid carries chunk (t & 7) of patch pixel (t >> 3)
+    unsigned pvo0[PIT_MAX], pvo1[PIT_MAX];
+#pragma unroll
+    for (int it = 0; it < PIT_MAX; ++it) {
+        const int t = it * 256 + tid;
+        const int pp = t >> 3;
+        const int c = (t & 7) ^ (pp & 7);
+        const int hy = pp / PW, hx = pp - hy * PW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = pp < npix && iy >= 0 && iy < Hd && ix >= 0 && ix < Wd;
+        const unsigned pix = (unsigned)((img * Hd + iy) * Wd + ix);
+        pvo0[it] = ok ? (pix * (unsigned)g.lda0 + (unsigned)c * 8u) * 2u : BL_OOB;
+        pvo1[it] = ok ? (pix * (unsigned)g.lda1 + (unsigned)c * 8u) * 2u : BL_OOB;
+    }
+
+    const int Ct = g.c0 + g.c1;
+    const int nch = Ct / BK;                       // 64-channel chunks over both sources
+    const int per = (nch + g.splitk - 1) / g.splitk;
+    const int ch_beg = split * per, ch_end = min(nch, ch_beg + per);
+
+    auto stage_patch = [&](int ch) {
+        const int cc = ch * BK;
+        const bool second = cc >= g.c0;
+        const unsigned chb = (unsigned)(second ? cc - g.c0 : cc) * 2;
+#pragma unroll
+        for (int it = 0; it < PIT_MAX; ++it) {
+            if (it < pit) {
+                if (!second) bl16(ra0, patch + (it * 256 + wave * 64) * 16, pvo0[it], chb);
+                else bl16(ra1, patch + (it * 256 + wave * 64) * 16, pvo1[it], chb);
+            }
+        }
+    };
+    auto stage_w = [&](int ch, int tap, int buf) {
+        char* sb = wbase + buf * WSTAGE;
+        const unsigned kb = (unsigned)(tap * Ct + ch * BK) * 2;
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) bl16(rw, sb + (it * 256 + wave * 64) * 16, wvo[it], kb);
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm0 = (wave / WGN) * WTM, wn0 = (wave % WGN) * WTN;
+    const int fr = lane & 15, fg = lane >> 4;
+    int prow[MF];  // patch pixel index of this lane's row for tap (0, 0)
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+        const int p = wm0 + j * 16 + fr;
+        const int ty = p / Wd, tx = p - ty * Wd;
+        prow[j] = ty * PW + tx;
+    }
+
+    auto compute = [&](int buf, int tap) {
+        const char* sw = wbase + buf * WSTAGE;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int toff = ky * PW + kx;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int physw = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            bf16x8 wf[NF], af[MF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sw + (wn0 + i * 16 + fr) * 128 + physw);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int pr = prow[j] + toff;
+                af[j] = *reinterpret_cast<const bf16x8*>(patch + pr * 128 + (((kk * 4 + fg) ^ (pr & 7)) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (ch_beg < ch_end) {
+        int cur = 0;
+        stage_w(ch_beg, 0, 0);
+        for (int ch = ch_beg; ch < ch_end; ++ch) {
+            stage_patch(ch);  // the previous chunk's last tap ended with a barrier: the patch buffer is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) stage_w(ch, tap + 1, cur ^ 1);
+                else if (ch + 1 < ch_end) stage_w(ch + 1, 0, cur ^ 1);
+                compute(cur, tap);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+
+    if (g.splitk > 1) {
+        float* part = g.partial + (size_t)split * (size_t)g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wm0 + j * 16 + fr;
+                const int n = n0 + wn0 + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4<float>(part + (size_t)m * g.N + n, v);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wm0 + j * 16 + fr;
+            const int n = n0 + wn0 + i * 16 + fg * 4;
+            if (m < g.M && n < g.N) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue4<T>(g, 0, m, n, v, nullptr);
+            }
+        }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const int nq = g.N >> 2;
@@ -833,6 +1020,67 @@ static int prepare_bls() {
 #undef X
     return 0;
 }
+// halo-conv configurations: id -> <BM, BN, WGM, WGN>
+#define HALO_CFGS(X)        \
+    X(41, 128, 160, 2, 2)   \
+    X(42, 128, 128, 2, 2)   \
+    X(43, 64, 160, 2, 2)    \
+    X(44, 128, 192, 2, 2)   \
+    X(45, 256, 64, 4, 1)
+
+static size_t halo_smem(const GemmArgs& g, int BM, int BN) {
+    const int TH = BM / g.Win;
+    const size_t npix = (size_t)(TH + 2) * (g.Win + 2);
+    const size_t patch = (npix * 8 + 255) / 256 * 4096;  // whole 256-lane DMA rounds
+    return patch + 2 * (size_t)BN * 128;
+}
+// eligibility of the halo kernel for a conv launch with M tile BM
+static bool halo_ok(const GemmArgs& g, int BM) {
+    if (!g.conv || g.stride != 1 || g.ups != 0 || g.zstuff || g.batch != 1) return false;
+    if (g.Win % 16 != 0 || g.Win > 64 || BM % g.Win != 0) return false;
+    if ((g.Hin * g.Win) % BM != 0 || g.M % BM != 0 || g.Hout != g.Hin || g.Wout != g.Win) return false;
+    const int npix = (BM / g.Win + 2) * (g.Win + 2);
+    const int pit_max = BM >= 256 ? 13 : (BM >= 128 ? 9 : 6);
+    return (npix * 8 + 255) / 256 <= pit_max && g.N % 4 == 0;
+}
+template <int BM, int BN, int WGM, int WGN>
+static int launch_halo(const GemmArgs& g, hipStream_t st) {
+    MRISR_REQUIRE(halo_ok(g, BM), "halo conv kernel: unsupported geometry");
+    const size_t smem = halo_smem(g, BM, BN);
+    MRISR_REQUIRE(smem <= 160 * 1024, "halo conv kernel: LDS");
+    static size_t attr = 0;
+    if (smem > attr) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_halo_kernel<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+        attr = 96 * 1024;
+    }
+    const int ntn = (g.N + BN - 1) / BN, ntm = g.M / BM;
+    dim3 grid(ntn * ntm, g.splitk, 1);
+    static const std::string base_name = std::string("gemm_bf16_halo") + std::to_string(BM) + "x" + std::to_string(BN);
+    std::string pname = base_name;
+    if (prof_enabled() && prof_shapes()) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s conv M=%d N=%d K=%d s=%d b=%d", base_name.c_str(), g.M, g.N, g.K, g.splitk, g.batch);
+        pname = buf;
+    }
+    double fl = g.alg_flops, by = g.alg_bytes;
+    if (prof_enabled()) {
+        if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K;
+        if (by == 0.0) by = 2.0 * ((double)g.B * g.Hin * g.Win * (g.c0 + g.c1) + (double)g.N * g.K + (double)g.M * g.N);
+    }
+    ProfScope ps(prof_intern(pname), fl, by, st);
+    hipLaunchKernelGGL((gemm_halo_kernel<BM, BN, WGM, WGN>), grid, dim3(256), smem, st, g);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+static int halo_bm(int tile) {
+    switch (tile) {
+#define X(id, bm, bn, wm, wn) case id: return bm;
+        HALO_CFGS(X)
+#undef X
+    }
+    return 0;
+}
+
 // buffer descriptors address at most 2^31 bytes per operand
 static bool bl_ok(const GemmArgs& g) {
     const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
@@ -977,9 +1225,10 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventCreate(&t0));
     MRISR_CHECK_HIP(hipEventCreate(&t1));
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
-    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
+    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
+        if (tile >= 40 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
         // 5 fragments per wave along N (BN = 160): no (u, gate) pairing for the GEGLU epilogue
         if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
@@ -1066,6 +1315,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         case 4: rc = launch_cfg<T, 64, 64, 2, 2>(g, st); break;
 #define X(id, bm, bn, wm, wn, ns) case id: rc = launch_bl<bm, bn, wm, wn, ns>(g, st); break;
         BL_CFGS(X)
+#undef X
+#define X(id, bm, bn, wm, wn) case id: rc = launch_halo<bm, bn, wm, wn>(g, st); break;
+        HALO_CFGS(X)
 #undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
     }

@@ -182,6 +182,27 @@ def test_conv3x3_buffer_addressed_kernel(tile, B, Cin, Cout, H, stride, ups, spl
     assert rel(y, ref) < TOL["bf16"]
 
 
+@pytest.mark.parametrize("tile,B,C1,C2,Cout,H,splitk", [
+    (41, 2, 64, 0, 320, 32, 1), (41, 1, 320, 0, 320, 16, 1), (41, 2, 128, 64, 160, 16, 1), (41, 1, 256, 0, 64, 32, 2),
+    (42, 2, 64, 0, 128, 32, 1), (42, 1, 128, 128, 320, 16, 2), (43, 3, 64, 0, 320, 16, 1), (43, 1, 128, 0, 100, 32, 1),
+    (44, 1, 64, 64, 384, 32, 1), (44, 2, 192, 0, 640, 16, 1), (45, 1, 64, 0, 64, 64, 1), (45, 2, 128, 0, 320, 16, 1),
+    (41, 1, 64, 0, 160, 64, 1),
+])
+def test_conv3x3_halo_kernel(tile, B, C1, C2, Cout, H, splitk):
+    """The LDS-halo conv kernel (the input neighbourhood staged once per 64-channel chunk, nine taps read shifted
+    fragments from it): every tile shape, image widths 16/32/64, skip-concat source, split over channel chunks,
+    ragged Cout, image borders (zero padding through out-of-range DMA) and tiles that start mid-image."""
+    from mrisr import ops
+    x1 = _rnd((B, C1, H, H), "bf16", 51)
+    x2 = _rnd((B, C2, H, H), "bf16", 52) if C2 else None
+    Cin = C1 + C2
+    w, b = _rnd((Cout, Cin, 3, 3), "f32", 53, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 54)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    ref = F.conv2d(xin, w.to(torch.bfloat16).float(), b, padding=1)
+    y = ops.conv3x3(x1.cuda(), w.cuda(), b.cuda(), x2=x2.cuda() if x2 is not None else None, tile=tile, splitk=splitk)
+    assert rel(y, ref) < TOL["bf16"]
+
+
 @pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 28, 29, 30])
 def test_buffer_addressed_kernel_concat_and_geglu(tile):
     from mrisr import _lib as L

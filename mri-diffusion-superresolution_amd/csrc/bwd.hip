@@ -335,7 +335,7 @@ __global__ void geglu_bwd_kernel(const T* __restrict__ pre, const T* __restrict_
         const int cu = (j >> 4) * 32 + (j & 15), cg = cu + 16;
         const float u = to_f32(pre[m * 2 * half + cu]), g = to_f32(pre[m * 2 * half + cg]);
         const float d = to_f32(dout[i]);
-        dpre[m * 2 * half + cu] = from_f32<T>(d * gelu_erf_f(g));
+        dpre[m * 2 * half + cu] = from_f32<T>(d * gelu_erf_t<T>(g));
         dpre[m * 2 * half + cg] = from_f32<T>(d * u * gelu_grad(g));
     }
 }
@@ -357,7 +357,7 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ out,
         const long long m = i / half;
         const int j = (int)(i - m * half);
         const int cu = (j >> 4) * 32 + (j & 15);
-        out[i] = from_f32<T>(to_f32(pre[m * 2 * half + cu]) * gelu_erf_f(to_f32(pre[m * 2 * half + cu + 16])));
+        out[i] = from_f32<T>(to_f32(pre[m * 2 * half + cu]) * gelu_erf_t<T>(to_f32(pre[m * 2 * half + cu + 16])));
     }
 }
 template <typename T>

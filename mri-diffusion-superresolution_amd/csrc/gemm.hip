@@ -76,7 +76,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
             load4<float>(g.bias + n0 + 16, bg);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (v[r] * alpha + bu[r]) * gelu_erf_f(vg[r] * alpha + bg[r]);
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] * alpha + bu[r]) * gelu_erf_t<T>(vg[r] * alpha + bg[r]);
         const int nc = (n0 >> 5) * 16 + (n0 & 15);
         T* o = reinterpret_cast<T*>(g.out) + (size_t)m * g.ldo + nc;
         store4<T>(o, v);

@@ -147,6 +147,32 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
  * schedule's own (t_i, t_{i+1}) pair, so a truncated run reproduces the prefix of the full trajectory. */
 int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step);
 
+/* ---- AutoencoderKL (SD-1.5 VAE): pixel <-> latent, once before / once after the sampling loop --------------
+ * Replaces vae.encode(x).latent_dist (res_srdiff.py:49-50) and vae.decode(z).sample (res_srdiff.py:107-110); the
+ * arithmetic is diffusers' AutoencoderKL (state-dict keys encoder.* / decoder.* / quant_conv / post_quant_conv).
+ *   encode: image [B,3,H,W] -> moments [B, 2*latent, H/8, W/8] = (mean | logvar) of the diagonal Gaussian posterior;
+ *           sampling (mean + exp(0.5*logvar)*eps) and the scaling_factor stay with the caller, as in the reference.
+ *   decode: latents [B,latent,h,w] (already divided by scaling_factor) -> image [B,3,8h,8w], NCHW in image->dtype. */
+typedef struct {
+    int32_t in_channels;           /* 3 */
+    int32_t out_channels;          /* 3 */
+    int32_t latent_channels;       /* 4 */
+    int32_t num_levels;            /* 4 */
+    int32_t block_out_channels[4]; /* 128, 256, 512, 512 */
+    int32_t layers_per_block;      /* 2 */
+    int32_t norm_num_groups;       /* 32 */
+    int32_t compute_dtype;         /* MRISR_BF16 or MRISR_F32 */
+    float scaling_factor;          /* 0.18215 (carried for the host mirror; not applied by encode / decode) */
+} mrisr_vae_cfg;
+typedef struct mrisr_vae mrisr_vae;
+int mrisr_vae_create(const mrisr_vae_cfg* cfg, mrisr_vae** out);
+void mrisr_vae_destroy(mrisr_vae* v);
+int mrisr_vae_set_param(mrisr_vae* v, const char* key, const float* data, const int64_t* shape, int ndim, int is_device);
+int64_t mrisr_vae_num_params(const mrisr_vae* v);
+int mrisr_vae_finalize(mrisr_vae* v, void* stream);
+int mrisr_vae_encode(mrisr_vae* v, const mrisr_tensor* image, mrisr_tensor* moments, void* stream);
+int mrisr_vae_decode(mrisr_vae* v, const mrisr_tensor* latents, mrisr_tensor* image, void* stream);
+
 /* ---- LoRA fine-tuning step ---------------------------------------------------
  * Replaces, for the UNet handle, what the reference's training cell gets from torch autograd + accelerate
  * (notebook ResDif c11:14-41: noise_pred = unet(noisy, t, ehs).sample; loss = mse(noise_pred, noise);

@@ -85,6 +85,8 @@ struct GemmArgs {
     int lda0 = 0, lda1 = 0;    // row pitch in elements
     int conv = 0;              // 0: plain rows, 1: 3x3 conv (pad 1)
     int B = 0, Hin = 0, Win = 0, Hout = 0, Wout = 0, stride = 1, ups = 0;
+    int pad = 1;               // zero padding on the low (top / left) side; the high side is whatever Hout / Wout imply
+                               // (pad = 0 with Hout = Hin / 2: diffusers' Downsample2D(padding=0), asymmetric (0,1,0,1))
     int zstuff = 0;            // with ups = 1: the x2 image is ZERO-STUFFED (odd rows/cols are 0) instead of nearest -
                                // the input of a stride-2 conv's dgrad (transposed convolution)
     // ---- W operand: [N][K] elements of T, K = taps*(c0+c1) ----

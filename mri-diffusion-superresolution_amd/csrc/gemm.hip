@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
             const int rem = m - b * hw;
             const int oy = rem / g.Wout;
             ab[it] = b;
-            ay[it] = oy * g.stride - 1;
-            ax[it] = (rem - oy * g.Wout) * g.stride - 1;
+            ay[it] = oy * g.stride - g.pad;
+            ax[it] = (rem - oy * g.Wout) * g.stride - g.pad;
             asrc0[it] = asrc1[it] = nullptr;
         }
     }
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
             const int rem = m - b * hw;
             const int oy = rem / g.Wout;
             ab[it] = b * g.Hin;
-            ay[it] = oy * g.stride - 1;
-            ax[it] = (rem - oy * g.Wout) * g.stride - 1;
+            ay[it] = oy * g.stride - g.pad;
+            ax[it] = (rem - oy * g.Wout) * g.stride - g.pad;
         }
     }
     const int acb = pch * 16;  // physical chunk byte offset is applied through `c` below for conv rows
@@ -1036,7 +1036,7 @@ static size_t halo_smem(const GemmArgs& g, int BM, int BN) {
 }
 // eligibility of the halo kernel for a conv launch with M tile BM
 static bool halo_ok(const GemmArgs& g, int BM) {
-    if (!g.conv || g.stride != 1 || g.ups != 0 || g.zstuff || g.batch != 1) return false;
+    if (!g.conv || g.stride != 1 || g.ups != 0 || g.zstuff || g.batch != 1 || g.pad != 1) return false;
     if (g.Win % 16 != 0 || g.Win > 64 || BM % g.Win != 0) return false;
     if ((g.Hin * g.Win) % BM != 0 || g.M % BM != 0 || g.Hout != g.Hin || g.Wout != g.Win) return false;
     const int npix = (BM / g.Win + 2) * (g.Win + 2);
@@ -1174,7 +1174,7 @@ template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);
 
 static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     char key[200];
-    snprintf(key, sizeof(key), "%d,%d,%d,c%d,s%d,u%d,%d,%d,a%d,o%d,b%d,r%d,v%d,h%d,w%d", g0.M, g0.N, g0.K, g0.conv, g0.stride, g0.ups, g0.c0,
+    snprintf(key, sizeof(key), "%d,%d,%d,c%d,s%d,u%d,%d,%d,a%d,o%d,b%d,r%d,v%d,h%d,w%d", g0.M, g0.N, g0.K, g0.conv, g0.stride + 8 * (1 - g0.pad), g0.ups, g0.c0,
              g0.c1, g0.act, g0.out_mode, g0.batch, g0.resid ? 1 : 0, g0.rowvec ? 1 : 0, g0.Hin, g0.Win);
     static bool cache_loaded = false;
     const char* cache_path = getenv("MRISR_TUNE_CACHE");  // optional on-disk table: "key<TAB>tile<TAB>split" per line

@@ -38,6 +38,12 @@ class AdapterCfg(C.Structure):
                 ("use_conv", C.c_int32), ("compute_dtype", C.c_int32)]
 
 
+class VaeCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("latent_channels", C.c_int32),
+                ("num_levels", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("layers_per_block", C.c_int32),
+                ("norm_num_groups", C.c_int32), ("compute_dtype", C.c_int32), ("scaling_factor", C.c_float)]
+
+
 class MrisrError(RuntimeError):
     pass
 
@@ -52,6 +58,8 @@ EXPORTS = [
     "mrisr_model_skip_shape", "mrisr_controlnet_forward", "mrisr_controlnet_set_cond", "mrisr_adapter_create",
     "mrisr_adapter_destroy", "mrisr_adapter_set_param", "mrisr_adapter_finalize", "mrisr_adapter_forward",
     "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range",
+    "mrisr_vae_create", "mrisr_vae_destroy", "mrisr_vae_set_param", "mrisr_vae_num_params", "mrisr_vae_finalize",
+    "mrisr_vae_encode", "mrisr_vae_decode",
     "mrisr_train_prepare", "mrisr_train_num_trainable", "mrisr_train_num_tensors", "mrisr_train_tensor_info",
     "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_optim_sumsq", "mrisr_optim_adamw",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
@@ -74,6 +82,10 @@ def lib() -> C.CDLL:
         L.mrisr_model_destroy.restype = None
         L.mrisr_adapter_destroy.restype = None
         L.mrisr_sampler_destroy.restype = None
+        L.mrisr_vae_destroy.restype = None
+        L.mrisr_vae_destroy.argtypes = [C.c_void_p]
+        L.mrisr_vae_num_params.restype = C.c_int64
+        L.mrisr_vae_num_params.argtypes = [C.c_void_p]
         for name in ("mrisr_model_destroy", "mrisr_adapter_destroy", "mrisr_sampler_destroy",
                      "mrisr_model_num_params", "mrisr_model_workspace_bytes", "mrisr_model_num_skips"):
             getattr(L, name).argtypes = [C.c_void_p]

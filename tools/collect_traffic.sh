@@ -17,6 +17,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 def cls(name):
     m = re.search(r"gemm_bl_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"gemm_bl_kernel<(\d+), (\d+),", name)
     if m: return f"gemm_bf16_bl{m.group(1)}x{m.group(2)}"
+    m = re.search(r"gemm_halo_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"gemm_halo_kernel<(\d+), (\d+),", name)
+    if m: return f"gemm_bf16_halo{m.group(1)}x{m.group(2)}"
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", name)
     if m: return f"gemm_{'bf16' if m.group(1) != 'f' else 'f32'}_{m.group(2)}x{m.group(3)}"
     for k, v in (("attn_fwd", "flash_attention"), ("gn_stats", "groupnorm_stats"), ("gn_apply", "groupnorm_apply"), ("layernorm", "layernorm"),

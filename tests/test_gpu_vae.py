@@ -74,3 +74,64 @@ def test_vae_reference_call_pattern_and_errors(tiny):
     v3 = mrisr.AutoencoderKL(cfg, compute_dtype="f32")
     with pytest.raises(mrisr.MrisrError, match="missing parameter: decoder.conv_out.weight"):
         v3.load_state_dict(bad)
+
+
+class _OracleVAE:
+    """The oracle VAE behind the same duck-typed surface (CPU): swapped in for mrisr.AutoencoderKL to check integration."""
+
+    def __init__(self, cfg, p):
+        self.cfg, self.p = cfg, p
+        self.config = type("C", (), {"scaling_factor": cfg.scaling_factor})
+
+    def encode(self, x):
+        from oracle import vae as ov
+        mom = ov.encode_moments(self.p, self.cfg, x.float().cpu()).to(x.device)
+        mean, logvar = mom.chunk(2, 1)
+
+        class D:
+            def sample(_s):
+                return mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * torch.randn(mean.shape).to(mean.device)
+        return type("E", (), {"latent_dist": D()})
+
+    def decode(self, z):
+        from oracle import vae as ov
+        return type("O", (), {"sample": ov.decode(self.p, self.cfg, z.float().cpu()).to(z.device)})
+
+
+def test_log_validation_with_device_vae(tiny):
+    """The reference's validation sampler end to end on the device (VAE encode -> ControlNet + UNet loop -> VAE decode ->
+    uint8 panel, res_srdiff.py:35-116): mrisr.AutoencoderKL in place of the VAE changes the panel by at most 1 LSB
+    against the CPU oracle VAE behind the same surface."""
+    import numpy as np
+    import mrisr
+    from oracle import unet as ou
+    cfg, p = tiny
+    ucfg = ou.TINY
+    up = ou.init_unet_params(ucfg, seed=101, perturb_norm=True)
+    cp = ou.init_controlnet_params(ucfg, seed=102, perturb_norm=True)
+    unet = mrisr.UNet2DConditionModel(ucfg, compute_dtype="f32")
+    unet.load_state_dict(up)
+    cnet = mrisr.ControlNetModel(ucfg, compute_dtype="f32")
+    cnet.load_state_dict(cp)
+    vae = mrisr.AutoencoderKL(cfg, compute_dtype="f32")
+    vae.load_state_dict(p)
+    gen = torch.Generator().manual_seed(11)
+    hr = torch.nn.functional.interpolate(torch.randn((1, 1, 32, 32), generator=gen), size=(512, 512), mode="bicubic").clamp(-1, 1)
+    lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 4), scale_factor=4.0, mode="bilinear")
+    ctx = torch.randn((1, 77, ucfg.cross_attention_dim), generator=gen).cuda()
+    sched = mrisr.DDPMScheduler(timestep_spacing="leading", steps_offset=1)
+    acc = type("A", (), {"device": torch.device("cuda")})
+    panels = []
+    orig = (torch.randn_like, torch.randn)
+    for v in (vae, _OracleVAE(cfg, p)):
+        torch.manual_seed(123)
+        torch.randn_like = lambda t, **kw: orig[1](t.shape).to(t.device, t.dtype)  # every draw from the CPU stream
+        try:
+            if v is vae:  # the device posterior draws through torch.randn(device=cuda): route it to the CPU stream too
+                torch.randn = lambda *a, **kw: orig[1](*a, **{k: w for k, w in kw.items() if k not in ("device", "generator")}).to(kw.get("device", "cpu"))
+            panels.append(np.asarray(mrisr.log_validation(unet, cnet, v, [{"hr": hr, "lr": lr}], sched, torch.float32, acc, ctx,
+                                                          num_inference_steps=4)).astype(int))
+        finally:
+            torch.randn_like, torch.randn = orig
+    assert panels[0].shape == panels[1].shape
+    assert np.abs(panels[0] - panels[1]).max() <= 1

@@ -22,6 +22,9 @@ __device__ __forceinline__ float xor_sum(float v) {
 }
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
 
 template <int DPAD, int DB, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
@@ -64,18 +67,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 
     // tile staging: global -> registers (issued a tile ahead) -> LDS
     bf16x8 kreg[CPT], vreg[CPT];
-    auto fetch = [&](int kt0) {
+    const bf16* kptr[CPT];
+    const bf16* vptr[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = i * 256 + tid;
+        kptr[i] = kb + (size_t)(c / (DPAD / 8)) * DPAD + (c % (DPAD / 8)) * 8;   // K tile: KT rows x DPAD/8 chunks
+        vptr[i] = vb + (size_t)(c >> 3) * a.nkpad + (c & 7) * 8;                 // V^T tile: DPAD rows x 8 chunks
+    }
+    auto fetch = [&](int kt0) {  // called with consecutive tiles: the pointers just advance
+        (void)kt0;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = i * 256 + tid;
-            {   // K tile: KT rows x DPAD/8 chunks
-                const int row = c / (DPAD / 8), ch = c % (DPAD / 8);
-                kreg[i] = *reinterpret_cast<const bf16x8*>(kb + (size_t)(kt0 + row) * DPAD + ch * 8);
-            }
-            {   // V^T tile: DPAD rows x 8 chunks
-                const int row = c >> 3, ch = c & 7;
-                vreg[i] = *reinterpret_cast<const bf16x8*>(vb + (size_t)row * a.nkpad + kt0 + ch * 8);
-            }
+            kreg[i] = *reinterpret_cast<const bf16x8*>(kptr[i]);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(vptr[i]);
+            kptr[i] += KT * DPAD;
+            vptr[i] += KT;
         }
     };
     auto commit = [&]() {
@@ -104,21 +111,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         // ---- S^T for 64 keys x (QF*16) queries: 4 key blocks of 16 ----
         f32x4 s[QF][4];
 #pragma unroll
-        for (int f = 0; f < QF; ++f)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) s[f][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
 #pragma unroll
-                for (int f = 0; f < QF; ++f) s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], s[f][tt], 0, 0, 0);
+                for (int f = 0; f < QF; ++f) {
+                    // first k-step: C = 0 as an inline constant (no zero-initialised accumulator registers)
+                    const f32x4 c = kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[f][tt];
+                    s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], c, 0, 0, 0);
+                }
             }
         }
         const bool ragged = kt0 + KT > a.nk;  // only the last tile can hold masked keys (uniform branch)
         // ---- online softmax, once per 64 keys: lane owns q = fr; its 16 values are keys 16tt + 4fg + r ----
-        bf16x8 pf[QF][2];
+        uint4v pw[QF][2];  // P^T fragments as packed bf16 pairs (second MFMA operand)
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             if (ragged) {
@@ -128,22 +135,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (kt0 + tt * 16 + fg * 4 + r >= a.nk) s[f][tt][r] = -INFINITY;
             }
-            float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
+            // the softmax is the VALU bound of this kernel (SQ counters: VALU busy 76 % of the SIMD's cycles): keep it
+            // to v_max3 chains and packed-f32 FMAs / adds (two values per instruction)
+            float mx = s[f][0][0];
 #pragma unroll
-            for (int tt = 1; tt < 4; ++tt) mx = fmaxf(mx, fmaxf(fmaxf(s[f][tt][0], s[f][tt][1]), fmaxf(s[f][tt][2], s[f][tt][3])));
+            for (int tt = 0; tt < 4; ++tt) {
+                mx = fmaxf(fmaxf(mx, s[f][tt][0]), s[f][tt][1]);
+                mx = fmaxf(fmaxf(mx, s[f][tt][2]), s[f][tt][3]);
+            }
             mx = xor_max(mx) * sl2;                       // running max kept in the scaled (log2) domain
             const float m_new = fmaxf(m_run[f], mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
             m_run[f] = m_new;
-            float ps = 0.f;
+            const f32x2 sl2v = {sl2, sl2}, nmv = {-m_new, -m_new};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[f][tt][r], sl2, -m_new));  // exp(scale*(s - max))
-                    ps += p;
-                    pf[f][tt >> 1][(tt & 1) * 4 + r] = (bf16)p;
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 x = {s[f][tt][r], s[f][tt][r + 1]};
+                    const f32x2 e = __builtin_elementwise_fma(x, sl2v, nmv);  // scale*(s - max) in log2 units
+                    const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                    ps2 += p;
+                    pw[f][tt >> 1][(tt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // one v_cvt_pk
                 }
+            const float ps = ps2[0] + ps2[1];
             l_run[f] = l_run[f] * alpha + ps;
 #pragma unroll
             for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
@@ -160,7 +176,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                 const short8v packed = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, packed);
 #pragma unroll
-                for (int f = 0; f < QF; ++f) oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f][sub], oacc[f][d], 0, 0, 0);
+                for (int f = 0; f < QF; ++f)
+                    oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[f][sub]), oacc[f][d], 0, 0, 0);
             }
         }
     }

@@ -204,6 +204,14 @@ int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_d
                       float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int step, void* stream);
 
+/* ---- image metrics of the reference's evaluator (src/eval/eval.py:15-51) --------------------------------------
+ * pred / gt: f32 [batch][height][width] in [0, 1] (the reference divides its 8-bit PNGs by 255).  out: f32 [batch][4] =
+ * {PSNR (torchmetrics, data_range 1), SSIM (torchmetrics defaults: 11x11 Gaussian sigma 1.5, k1 .01, k2 .03, mean over
+ * the fully-inside windows), HFEN (||LoG(pred) - LoG(gt)|| / (||LoG(gt)|| + 1e-8), sigma 1.5), NMSE}.
+ * scratch: 2*batch*height*width floats; sums: batch*6 doubles (zeroed here). */
+int mrisr_image_metrics(const float* pred_dev, const float* gt_dev, int batch, int height, int width, float* scratch_dev,
+                        double* sums_dev, float* out_dev, void* stream);
+
 /* ---- per-launch HIP-event profiler (bench.py roofline leg; off by default) ------------------------- */
 int mrisr_prof_enable(int on);
 int mrisr_prof_reset(void);

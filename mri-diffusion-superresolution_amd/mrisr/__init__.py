@@ -9,3 +9,4 @@ from .pipeline import (Sampler, decode_to_vis, get_res_shifting_latents, log_val
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
 from .train import LoRATrainer, cosine_lr  # noqa: F401
 from .vae import AutoencoderKL, VAEConfig, vae_param_shapes  # noqa: F401
+from .metrics import MRIEvaluator  # noqa: F401

@@ -60,6 +60,7 @@ EXPORTS = [
     "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range",
     "mrisr_vae_create", "mrisr_vae_destroy", "mrisr_vae_set_param", "mrisr_vae_num_params", "mrisr_vae_finalize",
     "mrisr_vae_encode", "mrisr_vae_decode",
+    "mrisr_image_metrics",
     "mrisr_train_prepare", "mrisr_train_num_trainable", "mrisr_train_num_tensors", "mrisr_train_tensor_info",
     "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_optim_sumsq", "mrisr_optim_adamw",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",

@@ -43,3 +43,18 @@ mse_i = float(((img(ref) - img(got)) ** 2).mean())
 print(f"stub-decoded slices in [0,1]: PSNR(bf16 vs f32) = {10 * math.log10(1.0 / max(mse_i, 1e-20)):.2f} dB; lr anchor PSNR vs f32 result = "
       f"{10 * math.log10(1.0 / float(((img(ref) - img(lr_lat.double().cpu())) ** 2).mean())):.2f} dB vs bf16 result = "
       f"{10 * math.log10(1.0 / float(((img(got) - img(lr_lat.double().cpu())) ** 2).mean())):.2f} dB")
+
+# ---- image domain: decode both results with the device VAE (SD-1.5 size, f32) and score them against the same ground truth
+# with the device metrics (the reference's evaluator: PSNR / SSIM / HFEN / NMSE on 8-bit grayscale) ----
+vae = mrisr.AutoencoderKL(mrisr.VAEConfig(), compute_dtype="f32")
+vae.load_state_dict(P.random_state_dict(mrisr.vae_param_shapes(mrisr.VAEConfig()), bench.SEED + 5, dev))
+ev = mrisr.MRIEvaluator()
+to_u8 = lambda im: ((im.mean(1, keepdim=True) / 2 + 0.5).clamp(0, 1) * 255).round() / 255  # noqa: E731  gray, 8-bit like the PNGs
+dec = {k: to_u8(vae.decode((v.float().to(dev)) / 0.18215).sample) for k, v in outs.items()}
+gt = to_u8(vae.decode(lr_lat.float() / 0.18215).sample)  # a fixed target: the decoded low-field anchor
+m32, m16 = ev.evaluate(dec["f32"], gt), ev.evaluate(dec["bf16"], gt)
+d = ev.evaluate(dec["bf16"], dec["f32"])
+print("decoded 256x256 slices (8-bit gray), mean over the batch:")
+for k in ("PSNR", "SSIM", "HFEN", "NMSE"):
+    print(f"  {k}: f32 vs target {float(m32[k].mean()):.4f} | bf16 vs target {float(m16[k].mean()):.4f} | "
+          f"|difference| max over slices {float((m32[k] - m16[k]).abs().max()):.4f} | bf16 vs f32 directly {float(d[k].mean()):.4f}")

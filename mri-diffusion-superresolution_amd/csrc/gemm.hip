@@ -888,6 +888,117 @@ __global__ __launch_bounds__(256) void gemm_halo_kernel(const GemmArgs g) {
         }
 }
 
+// =================================================================================================
+// Weight-stationary kernel for the short-K projections ("ws"): K = 32*KS fits a whole [16*NB rows][K] weight slab in
+// LDS (K = 320, BN = 160: 100 KB), so a workgroup loads its slab ONCE and then streams row blocks of the activation
+// through it.  The A fragments never touch LDS: every wave loads its own 32 rows straight from global memory into MFMA
+// operand layout (16 B per lane), a whole row block (all KS k-steps) at a time and one block ahead of the MFMAs, so
+// the only exposed latencies are the first block's and HBM streams continuously - the plain kernel above runs these
+// shapes as ONE lock-step wave of workgroups (five K tiles each: prologue, first-load latency and epilogue are not
+// amortised).  One workgroup per CU (the slab fills the LDS), grid = slabs x row groups.
+// Requirements: plain rows, no split, M % 128 == 0, N % (16*NB) == 0, K == 32*KS.  LORA as in gemm_bl_kernel.
+// =================================================================================================
+template <int KS, int NB, bool LORA>
+__global__ __launch_bounds__(256) void gemm_ws_kernel(const GemmArgs g, int row_groups) {
+    typedef bf16 T;
+    constexpr int K = KS * 32;
+    constexpr int BN = NB * 16;
+    constexpr int WP = K * 2 + 16;  // padded slab row pitch (bytes): conflict-free 16-byte fragment reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;                                    // [BN (+16 adapter rows)][WP]
+    float* zl = reinterpret_cast<float*>(smem + (BN + (LORA ? 16 : 0)) * WP);  // per wave [16][16] f32
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int slab = blockIdx.x / row_groups, rg = blockIdx.x - slab * row_groups;
+    const int n0 = slab * BN;
+    const T* ap = reinterpret_cast<const T*>(g.a0);
+    const T* wp = reinterpret_cast<const T*>(g.w);
+
+    // ---- the slab: global -> registers -> LDS, once ----
+    {
+        constexpr int CPR = K / 8;  // 16-byte chunks per row
+        const int rows = BN + (LORA ? 16 : 0);
+        for (int c = tid; c < rows * CPR; c += 256) {
+            const int row = c / CPR, ch = c - row * CPR;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (row < BN) v = *reinterpret_cast<const bf16x8*>(wp + (size_t)(n0 + row) * K + ch * 8);
+            else if (LORA && row - BN < g.lora_R) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(g.lora_a) + (size_t)(row - BN) * K + ch * 8);
+            *reinterpret_cast<bf16x8*>(wl + row * WP + ch * 16) = v;
+        }
+    }
+    // ---- row blocks of 64 (a wave: one 16-row fragment), strided over the row groups; one block prefetched ahead ----
+    const int nblk = g.M / 64;
+    bf16x8 a_cur[KS], a_nxt[KS];
+    auto load_a = [&](bf16x8 (&dst)[KS], int blk) {
+        const T* base = ap + (size_t)(blk * 64 + wave * 16 + fr) * g.lda0 + fg * 8;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(base + kk * 32);
+    };
+    int blk = rg;
+    if (blk < nblk) load_a(a_cur, blk);
+    __syncthreads();  // slab visible
+    float* zw = zl + wave * 16 * 16;
+    for (; blk < nblk; blk += row_groups) {
+        const int nb_next = blk + row_groups;
+        if (nb_next < nblk) load_a(a_nxt, nb_next);
+        f32x4 acc[NB];
+        f32x4 zacc;
+        // slab fragments software-pipelined one k-step ahead; the scheduling barriers keep the compiler from hoisting
+        // all KS*NB LDS reads to the top (it would need 4x the register file)
+        constexpr int NW = NB + (LORA ? 1 : 0);
+        bf16x8 wf[2][NW];
+        auto load_w = [&](bf16x8 (&dst)[NW], int kk) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(wl + (i * 16 + fr) * WP + (kk * 32 + fg * 8) * 2);
+        };
+        load_w(wf[0], 0);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const f32x4 c = kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], a_cur[kk], c, 0, 0, 0);
+            }
+            if (LORA) {  // the 16 adapter rows sit right behind the slab: fragment index NB
+                const f32x4 c = kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : zacc;
+                zacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][NW - 1], a_cur[kk], c, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int m = blk * 64 + wave * 16 + fr;
+        if (LORA) {  // z[q = 4fg + r][m = fr] -> this wave's LDS rows; every lane then reads its own row
+            *reinterpret_cast<f32x4*>(zw + fr * 16 + fg * 4) = zacc;
+            if (g.lora_zout && slab == 0 && fg * 4 < g.lora_R) *reinterpret_cast<f32x4*>(g.lora_zout + (size_t)m * g.lora_R + fg * 4) = zacc;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes have landed (wave-private rows)
+        }
+        if (g.act == ACT_GEGLU) {
+            if constexpr (NB % 2 == 0) {
+#pragma unroll
+                for (int i = 0; i < NB; i += 2) {
+                    float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                    float vg[4] = {acc[i + 1][0], acc[i + 1][1], acc[i + 1][2], acc[i + 1][3]};
+                    epilogue4<T>(g, 0, m, n0 + i * 16 + fg * 4, v, vg);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                epilogue4<T>(g, 0, m, n0 + i * 16 + fg * 4, v, nullptr, LORA ? zw + fr * 16 : nullptr);
+            }
+        }
+        if (nb_next < nblk) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a_cur[kk] = a_nxt[kk];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const int nq = g.N >> 2;
@@ -1081,6 +1192,69 @@ static int halo_bm(int tile) {
     return 0;
 }
 
+// weight-stationary configurations: id -> <KS, NB>   (K = 32*KS, slab of 16*NB output columns)
+#define WS_CFGS(X)   \
+    X(50, 10, 10)    \
+    X(51, 10, 8)     \
+    X(52, 20, 4)
+
+static void ws_dims(int tile, int* ks, int* nb) {
+    *ks = *nb = 0;
+    switch (tile) {
+#define X(id, k, n) case id: *ks = k; *nb = n; break;
+        WS_CFGS(X)
+#undef X
+    }
+}
+static bool ws_ok(const GemmArgs& g, int tile) {
+    int ks, nb;
+    ws_dims(tile, &ks, &nb);
+    if (!ks || g.conv || g.c1 || g.batch != 1 || g.a1) return false;
+    if (g.K != 32 * ks || g.N % (16 * nb) != 0 || g.M % 64 != 0 || g.lda0 % 8 != 0) return false;
+    if (g.act == ACT_GEGLU && (nb & 1)) return false;
+    if (g.out_mode == OUT_NONE) return false;
+    return true;
+}
+template <int KS, int NB>
+static int launch_ws(const GemmArgs& g, hipStream_t st) {
+    constexpr int K = KS * 32, BN = NB * 16, WP = K * 2 + 16;
+    MRISR_REQUIRE(g.splitk == 1, "weight-stationary kernel: no split-K");
+    MRISR_REQUIRE(!g.conv && !g.c1 && !g.a1 && g.batch == 1 && g.K == K && g.N % BN == 0 && g.M % 64 == 0 && g.lda0 % 8 == 0 &&
+                      (g.act != ACT_GEGLU || NB % 2 == 0),
+                  "weight-stationary kernel: plain rows, K = 32*KS, N a multiple of the slab, M a multiple of 64");
+    const bool lora = g.lora_a != nullptr;
+    if (lora) MRISR_REQUIRE(g.lora_R >= 1 && g.lora_R <= 16 && g.lora_b && g.act != ACT_GEGLU, "in-kernel LoRA down-projection: R <= 16");
+    const size_t smem = (size_t)(BN + (lora ? 16 : 0)) * WP + (lora ? 4 * 16 * 16 * sizeof(float) : 0);
+    static bool attr = false;
+    if (!attr) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ws_kernel<KS, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ws_kernel<KS, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    MRISR_REQUIRE(smem <= 150 * 1024, "weight-stationary kernel: LDS");
+    const int slabs = g.N / BN, nblk = g.M / 64;
+    int rgroups = 256 / slabs;
+    if (rgroups < 1) rgroups = 1;
+    if (rgroups > nblk) rgroups = nblk;
+    static const std::string base_name = std::string("gemm_bf16_ws") + std::to_string(K) + "x" + std::to_string(BN);
+    std::string pname = base_name;
+    if (prof_enabled() && prof_shapes()) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s lin M=%d N=%d K=%d s=1 b=1", base_name.c_str(), g.M, g.N, g.K);
+        pname = buf;
+    }
+    double fl = g.alg_flops, by = g.alg_bytes;
+    if (prof_enabled()) {
+        if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K;
+        if (by == 0.0) by = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+    }
+    ProfScope ps(prof_intern(pname), fl, by, st);
+    if (lora) hipLaunchKernelGGL((gemm_ws_kernel<KS, NB, true>), dim3(slabs * rgroups), dim3(256), smem, st, g, rgroups);
+    else hipLaunchKernelGGL((gemm_ws_kernel<KS, NB, false>), dim3(slabs * rgroups), dim3(256), smem, st, g, rgroups);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // buffer descriptors address at most 2^31 bytes per operand
 static bool bl_ok(const GemmArgs& g) {
     const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
@@ -1225,15 +1399,18 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventCreate(&t0));
     MRISR_CHECK_HIP(hipEventCreate(&t1));
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
+    // 50-52 (weight-stationary short-K kernels) are NOT candidates: correct, but 30-60 % slower than the tiled kernels on
+    // every shape they fit (profiles/r01b_ws_sweep.log: one A fragment per wave makes them LDS-read bound); kept for the record
     static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
-        if (tile >= 40 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
+        if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
+        if (tile >= 50 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
         // 5 fragments per wave along N (BN = 160): no (u, gate) pairing for the GEGLU epilogue
         if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
         for (int s = 1; s <= 32; s *= 2) {
-            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096)) break;
+            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50)) break;
             const size_t pbytes = s > 1 ? (size_t)s * g.M * g.N * 4 * zb : 0;
             if (pbytes > ((size_t)1 << 30)) break;
             if (s > 1 && g_ts.reserve(4, pbytes, false)) return 1;
@@ -1272,9 +1449,18 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
 }
 
 // Chooses tile + split-K for g (sets g.tile / g.splitk).  Deterministic per signature within a process.
+static int g_prefer_tile = 0;  // test hook: use this specialised kernel (halo 41-45 / weight-stationary 50-52) wherever it is eligible
+extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
+
 int gemm_choose(GemmArgs& g, bool is_bf16) {
     int t = 0, s = 1;
     if (g_force_tile) { g.tile = g_force_tile; if (g.splitk < 1) g.splitk = 1; return 0; }
+    if (g_prefer_tile && is_bf16 && bl_ok(g) &&
+        ((g_prefer_tile >= 50 && ws_ok(g, g_prefer_tile)) || (g_prefer_tile >= 40 && g_prefer_tile < 50 && halo_ok(g, halo_bm(g_prefer_tile))))) {
+        g.tile = g_prefer_tile;
+        g.splitk = 1;
+        return 0;
+    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (is_bf16 && bl_ok(g) && autotune_enabled()) {
         if (tune(g, &t, &s)) return 1;
@@ -1318,6 +1504,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 #undef X
 #define X(id, bm, bn, wm, wn) case id: rc = launch_halo<bm, bn, wm, wn>(g, st); break;
         HALO_CFGS(X)
+#undef X
+#define X(id, ks, nb) case id: rc = launch_ws<ks, nb>(g, st); break;
+        WS_CFGS(X)
 #undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
     }

@@ -203,6 +203,49 @@ def test_conv3x3_halo_kernel(tile, B, C1, C2, Cout, H, splitk):
     assert rel(y, ref) < TOL["bf16"]
 
 
+@pytest.mark.parametrize("tile,M,N,K", [(50, 256, 320, 320), (50, 4096, 960, 320), (50, 64, 160, 320), (51, 320, 640, 320), (51, 1024, 128, 320),
+                                        (52, 192, 640, 640), (52, 2048, 64, 640)])
+def test_linear_weight_stationary_kernel(tile, M, N, K):
+    """The weight-stationary short-K kernel (slab of the weight resident in LDS, activation fragments straight from global
+    memory one row block ahead): bias, residual in place, GEGLU, several row blocks per workgroup."""
+    from mrisr import _lib as L
+    from mrisr import ops
+    x, w, b = _rnd((M, K), "bf16", 61), _rnd((N, K), "f32", 62, K ** -0.5), _rnd((N,), "f32", 63)
+    ref = F.linear(x.float(), w.to(torch.bfloat16).float(), b)
+    assert rel(ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=tile), ref) < TOL["bf16"]
+    if N % 32 == 0:
+        u, g = ref.chunk(2, dim=-1)
+        assert rel(ops.linear(x.cuda(), w.cuda(), b.cuda(), act=L.ACT_GEGLU, tile=tile), u * F.gelu(g)) < TOL["bf16"]
+
+
+def test_unet_with_specialised_kernels_preferred():
+    """SD-1.5 channel widths at a tiny spatial size, bf16 + explicit LoRA: the same forward with the autotuner's choice and
+    with the weight-stationary / halo kernels preferred wherever they are eligible (incl. the in-kernel LoRA
+    down-projection inside the weight-stationary kernel) - all within the bf16 bound of the CPU oracle."""
+    import ctypes as C
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg = ou.UNetConfig(block_out_channels=(320, 640), attn_levels=(True, True), cross_attention_dim=64)
+    up = ou.init_unet_params(cfg, seed=71, perturb_norm=True)
+    lora = ou.init_lora_params(up, rank=4, seed=72)
+    g = torch.Generator().manual_seed(73)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, 64), generator=g)
+    t = torch.tensor([40, 700])
+    ref = ou.unet_forward({**up, **lora}, cfg, x, t, ctx)
+    lib = L.lib()
+    try:
+        for pref in (0, 50, 52, 41, 43):
+            lib.mrisr_debug_prefer_tile(C.c_int(pref))
+            net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
+            net.load_state_dict({**up, **lora})
+            out = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+            assert rel(out, ref) < 5e-2, (pref, rel(out, ref))
+    finally:
+        lib.mrisr_debug_prefer_tile(C.c_int(0))
+
+
 @pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 28, 29, 30])
 def test_buffer_addressed_kernel_concat_and_geglu(tile):
     from mrisr import _lib as L

@@ -147,6 +147,20 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
  * schedule's own (t_i, t_{i+1}) pair, so a truncated run reproduces the prefix of the full trajectory. */
 int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step);
 
+/* ---- T2I-Adapter training (in BASELINE config 3 the adapter runs, and is differentiated, every step)
+ * Same ownership model as the LoRA step: the caller owns ONE flat f32 vector of all adapter parameters (PyTorch layouts,
+ * state-dict keys via tensor_info) and its gradient.  After train_prepare / train_bind, mrisr_adapter_forward keeps what the
+ * backward needs; mrisr_adapter_backward takes the gradients w.r.t. the four feature maps (what mrisr_train_step wrote
+ * through mrisr_train_set_intrablock_grads) and ADDS dW, db of every conv to the gradient vector (dgrad convs + one
+ * pixel-contraction GEMM per filter tap).  refresh re-packs the kernels' weight layouts after the optimiser step. */
+int mrisr_adapter_train_prepare(mrisr_adapter* a, void* stream);
+int64_t mrisr_adapter_train_num_trainable(const mrisr_adapter* a);
+int mrisr_adapter_train_num_tensors(const mrisr_adapter* a);
+int mrisr_adapter_train_tensor_info(const mrisr_adapter* a, int i, const char** key, int64_t* offset, int64_t shape[4], int* ndim);
+int mrisr_adapter_train_bind(mrisr_adapter* a, float* theta_dev, float* grad_dev, int init_from_model, void* stream);
+int mrisr_adapter_train_refresh(mrisr_adapter* a, void* stream);
+int mrisr_adapter_backward(mrisr_adapter* a, const mrisr_tensor* d_feats, int n_feats, void* stream);
+
 /* ---- AutoencoderKL (SD-1.5 VAE): pixel <-> latent, once before / once after the sampling loop --------------
  * Replaces vae.encode(x).latent_dist (res_srdiff.py:49-50) and vae.decode(z).sample (res_srdiff.py:107-110); the
  * arithmetic is diffusers' AutoencoderKL (state-dict keys encoder.* / decoder.* / quant_conv / post_quant_conv).
@@ -199,6 +213,9 @@ int mrisr_train_refresh(mrisr_model* m, void* stream);
 int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
                      const mrisr_tensor* intrablock, int n_intrablock, const mrisr_tensor* target, float* loss_dev,
                      mrisr_tensor* pred_out, void* stream);
+/* Gradients w.r.t. the T2I-Adapter features (intrablock[i] of the following mrisr_train_step calls) are written to
+ * grads[i] (same shapes; NCHW f32/bf16 or NHWC compute dtype) for the adapter's own backward; n = 0 switches it off. */
+int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, int n);
 int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream);
 int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, const float* sumsq_dev,
                       float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -843,6 +843,110 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long long n, cons
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// convolution weight gradients (T2I-Adapter training).  dW[co][ci][tap] = sum_m dY[m][co] * X[pix(m, tap)][ci] is run as one
+// GEMM per tap with the pixel index m as the contraction: both operands are needed "pixel-contiguous", i.e. transposed.
+//   im2col_tap_T: Xt[ci][m] = X[b][oy*stride + ky - pad][ox*stride + kx - pad][ci] (0 outside the image, 0 for m >= M)
+//   (dY^T comes from launch_transpose);  the GEMM writes f32 [Cout][Cin]; wgrad_accum folds it into the flat gradient in
+//   PyTorch's [Cout][Cin][kh][kw] layout; colsum gives the bias gradient.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_tap_T_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C, int Ho,
+                                                           int Wo, int stride, int pad, int ky, int kx, int M, int Mpad) {
+    __shared__ T tile[32][33];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int m = m0 + i, c = c0 + tx;
+        T v = from_f32<T>(0.f);
+        if (m < M && c < C) {
+            const int hw = Ho * Wo;
+            const int b = m / hw, r = m - b * hw;
+            const int oy = r / Wo, ox = r - oy * Wo;
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * H + iy) * W + ix) * C + c];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, m = m0 + tx;
+        if (c < C && m < Mpad) out[(size_t)c * Mpad + m] = tile[tx][i];
+    }
+}
+template <typename T>
+int launch_im2col_tap_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ky, int kx,
+                        int Mpad, hipStream_t st) {
+    const int M = B * Ho * Wo;
+    MRISR_REQUIRE(Mpad >= M, "im2col: padded pixel count");
+    ProfScope ps("im2col_tap_T", 0.0, 2.0 * M * (double)C * sizeof(T), st);
+    hipLaunchKernelGGL(im2col_tap_T_kernel<T>, dim3((Mpad + 31) / 32, (C + 31) / 32), dim3(256), 0, st, reinterpret_cast<const T*>(x),
+                       reinterpret_cast<T*>(out), B, H, W, C, Ho, Wo, stride, pad, ky, kx, M, Mpad);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// out = h > 0 ? dy : 0   (backward of ReLU; h is the ReLU's OUTPUT; out may alias dy)
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ h, T* out, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = to_f32(h[i]) > 0.f ? dy[i] : from_f32<T>(0.f);
+}
+template <typename T>
+int launch_relu_bwd(const void* dy, const void* h, void* out, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(bw_blocks(n)), dim3(256), 0, st, reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(h),
+                       reinterpret_cast<T*>(out), n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// out[c] += sum_m dy[m][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* out, int M, int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int m_beg = blockIdx.y * rows_per_block, m_end = min(M, m_beg + rows_per_block);
+    float acc = 0.f;
+    if (c < C)
+        for (int m = m_beg + sub; m < m_end; m += 4) acc += to_f32(dy[(size_t)m * C + c]);
+    red[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <typename T>
+int launch_colsum(const void* dy, float* out, int M, int C, hipStream_t st) {
+    const int rpb = 512;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, reinterpret_cast<const T*>(dy), out, M, C, rpb);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// gw[i * taps + tap] += tmp[i]   (tmp: this tap's [Cout][Cin] product)
+__global__ void wgrad_accum_kernel(const float* __restrict__ tmp, float* gw, long long n, int taps, int tap) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) gw[i * taps + tap] += tmp[i];
+}
+int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_accum_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, tmp, gw, n, taps, tap);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// dgrad filter bank of a 3x3 conv: wd[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]  (w: PyTorch f32 [Cout][Cin][3][3])
+template <typename T>
+__global__ void pack_conv_dgrad2_kernel(const float* __restrict__ w, T* __restrict__ wd, int Cout, int Cin) {
+    const long long total = (long long)Cout * Cin * 9;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const int t = (int)((i / Cout) % 9);
+        const int ci = (int)(i / (9ll * Cout));
+        const int ky = t / 3, kx = t - ky * 3;
+        wd[i] = from_f32<T>(w[(((size_t)co * Cin + ci) * 3 + (2 - ky)) * 3 + (2 - kx)]);
+    }
+}
+template <typename T>
+int launch_pack_conv_dgrad(const float* w, void* wd, int Cout, int Cin, hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv_dgrad2_kernel<T>, dim3(bw_blocks((long long)Cout * Cin * 9)), dim3(256), 0, st, w, reinterpret_cast<T*>(wd), Cout, Cin);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 #define BWD_INST(T)                                                                                                         \
     template int launch_groupnorm_bwd<T>(const GroupNormBwdArgs&, hipStream_t);                                             \
     template int launch_layernorm_bwd<T>(const void*, const void*, void*, const float*, int, int, float, int, hipStream_t); \
@@ -854,7 +958,11 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long long n, cons
     template int launch_lora_wgrad<T>(const void*, int, const float*, int, int, int, int, int, int, int, float* const[3],   \
                                       float, float*, hipStream_t);                                                          \
     template int launch_sumpool2<T>(const void*, void*, int, int, int, int, int, hipStream_t);                              \
-    template int launch_mse_grad<T>(const void*, const float*, void*, float*, int, int, int, int, hipStream_t);
+    template int launch_mse_grad<T>(const void*, const float*, void*, float*, int, int, int, int, hipStream_t);                  \
+    template int launch_im2col_tap_T<T>(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t); \
+    template int launch_relu_bwd<T>(const void*, const void*, void*, long long, hipStream_t);                                   \
+    template int launch_colsum<T>(const void*, float*, int, int, hipStream_t);                                                   \
+    template int launch_pack_conv_dgrad<T>(const float*, void*, int, int, hipStream_t);
 BWD_INST(float)
 BWD_INST(bf16)
 

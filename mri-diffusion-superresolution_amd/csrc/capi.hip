@@ -348,6 +348,14 @@ struct AdBlock {
     ConvW down_w, in_w, b1, b2;
     int in_c = 0, out_c = 0;
 };
+struct AdRec {  // what one block's backward needs (activations stay in the arena until the next forward)
+    Act x_in, x_down, x_pre, hmid, y;
+};
+struct AdTrainable {
+    std::string key;
+    long long offset = 0, numel = 0;
+    std::vector<int64_t> shape;
+};
 struct mrisr_adapter {
     mrisr_adapter_cfg cfg{};
     std::map<std::string, RawParam> raw;
@@ -356,6 +364,24 @@ struct mrisr_adapter {
     std::vector<AdBlock> blocks;
     Arena arena;
     bool finalized = false;
+    // ---- training (the adapter runs and is differentiated every step) ----
+    bool train_ready = false, recorded = false;
+    std::vector<AdTrainable> trainables;
+    long long n_trainable = 0;
+    float* theta = nullptr;
+    float* grad = nullptr;
+    Act rec_u;
+    std::vector<AdRec> recs;
+    std::vector<ConvW*> all_convs() {
+        std::vector<ConvW*> v{&conv_in};
+        for (auto& b : blocks) {
+            if (b.down) v.push_back(&b.down_w);
+            if (b.has_in) v.push_back(&b.in_w);
+            v.push_back(&b.b1);
+            v.push_back(&b.b2);
+        }
+        return v;
+    }
 };
 
 template <typename T>
@@ -394,6 +420,117 @@ struct AdRunner {
         if (dry) return 0;
         return launch_gemm<T>(g, st);
     }
+    // ---- backward building blocks ----
+    void* alloc(size_t bytes) {
+        void* p = a.arena.alloc(bytes);
+        if (!p) set_error("adapter workspace exhausted");
+        return p;
+    }
+    int gemm(GemmArgs& g) {
+        TRY(gemm_choose(g, sizeof(T) == 2));
+        if (g.splitk > 1) {
+            g.partial = static_cast<float*>(alloc((size_t)g.splitk * g.M * g.N * sizeof(float)));
+            if (!g.partial) return 7;
+        }
+        if (dry) return 0;
+        return launch_gemm<T>(g, st);
+    }
+    // dX = dgrad(dY) (+ resid);  3x3: conv with the flipped / transposed bank, stride 2 through zero-stuffing;  1x1: dY W
+    int conv_dgrad(const Act& dy, const ConvW& cw, int stride, const Act* resid, Act* dx) {
+        MRISR_REQUIRE(cw.wd && dy.C == cw.cout, "adapter dgrad weights");
+        const int up = stride == 2 ? 1 : 0;
+        *dx = new_act(dy.B, dy.H << up, dy.W << up, cw.cin);
+        if (!dx->p) return 7;
+        GemmArgs g;
+        g.a0 = dy.p; g.c0 = cw.cout; g.lda0 = cw.cout;
+        g.w = cw.wd; g.N = cw.cin; g.out = dx->p; g.ldo = cw.cin;
+        if (cw.ks == 3) {
+            g.conv = 1; g.B = dy.B; g.Hin = dy.H; g.Win = dy.W; g.Hout = dy.H << up; g.Wout = dy.W << up; g.stride = 1; g.ups = up; g.zstuff = up;
+            g.M = dy.B * g.Hout * g.Wout; g.K = 9 * cw.cout;
+        } else {
+            g.M = (int)dy.rows(); g.K = cw.cout;
+        }
+        if (resid) { g.resid = resid->p; g.ldr = resid->C; }
+        return gemm(g);
+    }
+    // dW, db of y = conv(x): one GEMM per tap over the pixel index (operands transposed into pixel-major scratch)
+    int conv_wgrad(const Act& x, const Act& dy, const ConvW& cw, int stride) {
+        MRISR_REQUIRE(cw.offW >= 0 && a.grad, "adapter gradient vector not bound");
+        const int M = (int)dy.rows(), Mpad = (M + 63) / 64 * 64, taps = cw.ks * cw.ks, pad = cw.ks / 2;
+        const size_t mk = a.arena.mark();
+        T* dyT = static_cast<T*>(alloc((size_t)cw.cout * Mpad * sizeof(T)));
+        T* xT = static_cast<T*>(alloc((size_t)cw.cin * Mpad * sizeof(T)));
+        float* tmp = static_cast<float*>(alloc((size_t)cw.cout * cw.cin * sizeof(float)));
+        if (!dyT || !xT || !tmp) return 7;
+        if (!dry) {
+            if (Mpad != M) MRISR_CHECK_HIP(hipMemsetAsync(dyT, 0, (size_t)cw.cout * Mpad * sizeof(T), st));
+            TRY(launch_transpose<T>(dy.p, dyT, M, cw.cout, cw.cout, Mpad, 0, 0, 1, M, st));
+            if (cw.offB >= 0) TRY(launch_colsum<T>(dy.p, a.grad + cw.offB, M, cw.cout, st));
+        }
+        for (int tap = 0; tap < taps; ++tap) {
+            if (!dry) TRY(launch_im2col_tap_T<T>(x.p, xT, x.B, x.H, x.W, x.C, dy.H, dy.W, stride, pad, tap / cw.ks, tap % cw.ks, Mpad, st));
+            GemmArgs g;
+            g.a0 = dyT; g.c0 = Mpad; g.lda0 = Mpad;
+            g.w = xT; g.M = cw.cout; g.N = cw.cin; g.K = Mpad;
+            g.out_mode = OUT_F32; g.out = tmp; g.ldo = cw.cin;
+            const size_t mk2 = a.arena.mark();
+            TRY(gemm(g));
+            a.arena.release(mk2);
+            if (!dry) TRY(launch_wgrad_accum(tmp, a.grad + cw.offW, (long long)cw.cout * cw.cin, taps, tap, st));
+        }
+        a.arena.release(mk);
+        return 0;
+    }
+    // d_feats: gradients w.r.t. the four feature maps (what mrisr_train_step wrote through mrisr_train_set_intrablock_grads)
+    int backward(const mrisr_tensor* d_feats, int n_feats) {
+        MRISR_REQUIRE(a.recorded || dry, "run the adapter forward first");
+        MRISR_REQUIRE(n_feats * a.cfg.nums_rb == (int)a.blocks.size(), "one feature gradient per level");
+        Act dcur;
+        for (int k = (int)a.blocks.size() - 1; k >= 0; --k) {
+            AdBlock& b = a.blocks[k];
+            AdRec& r = a.recs[k];
+            if ((k + 1) % a.cfg.nums_rb == 0) {
+                const mrisr_tensor& f = d_feats[(k + 1) / a.cfg.nums_rb - 1];
+                MRISR_REQUIRE(f.ndim == 4 && f.shape[0] == r.y.B && f.shape[1] == r.y.C && f.shape[2] == r.y.H && f.shape[3] == r.y.W,
+                              "adapter feature gradient shape");
+                Act gf = new_act(r.y.B, r.y.H, r.y.W, r.y.C);
+                if (!gf.p) return 7;
+                if (!dry) {
+                    if (f.layout == MRISR_NHWC) {
+                        MRISR_REQUIRE(f.dtype == a.cfg.compute_dtype, "NHWC feature gradients use the compute dtype");
+                        MRISR_CHECK_HIP(hipMemcpyAsync(gf.p, f.data, gf.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
+                    } else {
+                        TRY(launch_nchw_to_nhwc<T>(f.data, f.dtype, gf.p, gf.B, gf.C, gf.H, gf.W, st));
+                    }
+                    if (dcur.p) TRY(launch_add_inplace<T>(gf.p, dcur.p, (long long)gf.numel(), st));
+                }
+                dcur = gf;
+            }
+            MRISR_REQUIRE(dcur.p, "no gradient reaches the last adapter block");
+            // y = block2(relu(block1(x_pre))) + x_pre
+            TRY(conv_wgrad(r.hmid, dcur, b.b2, 1));
+            Act dh, dx;
+            TRY(conv_dgrad(dcur, b.b2, 1, nullptr, &dh));
+            if (!dry) TRY(launch_relu_bwd<T>(dh.p, r.hmid.p, dh.p, (long long)dh.numel(), st));
+            TRY(conv_wgrad(r.x_pre, dh, b.b1, 1));
+            TRY(conv_dgrad(dh, b.b1, 1, &dcur, &dx));
+            if (b.has_in) {
+                TRY(conv_wgrad(r.x_down, dx, b.in_w, 1));
+                Act d2;
+                TRY(conv_dgrad(dx, b.in_w, 1, nullptr, &d2));
+                dx = d2;
+            }
+            if (b.down) {
+                TRY(conv_wgrad(r.x_in, dx, b.down_w, 2));
+                Act d2;
+                TRY(conv_dgrad(dx, b.down_w, 2, nullptr, &d2));
+                dx = d2;
+            }
+            dcur = dx;
+        }
+        return conv_wgrad(a.rec_u, dcur, a.conv_in, 1);
+    }
+
     int forward(const mrisr_tensor& x, mrisr_tensor* feats, int n_feats) {
         a.arena.reset();
         const int B = (int)x.shape[0], C = (int)x.shape[1], H = (int)x.shape[2], W = (int)x.shape[3];
@@ -403,15 +540,23 @@ struct AdRunner {
         if (!dry) TRY(launch_pixel_unshuffle_nchw<T>(x.data, x.dtype, u.p, B, C, H, W, 8, st));
         Act cur;
         TRY(conv(u, a.conv_in, 1, ACT_NONE, nullptr, &cur));
+        a.rec_u = u;
+        a.recs.assign(a.blocks.size(), AdRec());
         int fi = 0;
         for (size_t k = 0; k < a.blocks.size(); ++k) {
             AdBlock& b = a.blocks[k];
+            AdRec& rec = a.recs[k];
             Act y;
+            rec.x_in = cur;
             if (b.down) { TRY(conv(cur, b.down_w, 2, ACT_NONE, nullptr, &y)); cur = y; }
+            rec.x_down = cur;
             if (b.has_in) { TRY(conv(cur, b.in_w, 1, ACT_NONE, nullptr, &y)); cur = y; }
+            rec.x_pre = cur;
             Act hmid;
             TRY(conv(cur, b.b1, 1, ACT_RELU, nullptr, &hmid));
             TRY(conv(hmid, b.b2, 1, ACT_NONE, &cur, &y));
+            rec.hmid = hmid;
+            rec.y = y;
             cur = y;
             if ((k + 1) % a.cfg.nums_rb == 0) {
                 MRISR_REQUIRE(fi < n_feats, "too few feature outputs");
@@ -443,6 +588,7 @@ static int adapter_finalize_t(mrisr_adapter& a, hipStream_t st) {
         if (it == a.raw.end()) { set_error("missing parameter: " + name + ".weight"); err = 3; return c; }
         const RawParam& w = it->second;
         c.cout = (int)w.shape[0]; c.cin = (int)w.shape[1]; c.ks = (int)w.shape[2];
+        c.name = name;
         a.packed.emplace_back(new DevBuf());
         if (a.packed.back()->reserve((size_t)w.numel() * sizeof(T), false)) { err = 4; return c; }
         c.w = a.packed.back()->p;
@@ -481,6 +627,18 @@ static int adapter_finalize_t(mrisr_adapter& a, hipStream_t st) {
     return 0;
 }
 
+// re-pack every conv of the adapter (forward bank, dgrad bank, bias pointer) from the bound trainable vector
+template <typename T>
+static int adapter_repack_t(mrisr_adapter& a, hipStream_t st) {
+    for (ConvW* c : a.all_convs()) {
+        const float* w = a.theta + c->offW;
+        TRY(launch_pack_conv3x3<T>(w, c->w, c->cout, c->cin, c->ks, st));
+        if (c->ks == 3) TRY(launch_pack_conv_dgrad<T>(w, c->wd, c->cout, c->cin, st));
+        else TRY(launch_transpose<T>(c->w, c->wd, c->cout, c->cin, c->cin, c->cout, 0, 0, 1, c->cout, st));
+        if (c->offB >= 0) c->b = a.theta + c->offB;
+    }
+    return 0;
+}
 extern "C" {
 
 int mrisr_adapter_create(const mrisr_adapter_cfg* cfg, mrisr_adapter** out) {
@@ -525,14 +683,88 @@ int mrisr_adapter_forward(mrisr_adapter* a, const mrisr_tensor* x, mrisr_tensor*
     // size the arena with a dry pass (exact), then run
     int rc;
     a->arena.dry = true; a->arena.reset(); a->arena.peak = 0;
-    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, true}; rc = r.forward(*x, feats, n_feats); }
-    else { AdRunner<bf16> r{*a, st, true}; rc = r.forward(*x, feats, n_feats); }
+    a->recorded = false;
+    // training: the backward continues in the same arena (the activations must stay put), so size it for both now
+    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, true}; rc = r.forward(*x, feats, n_feats); if (!rc && a->train_ready) rc = r.backward(feats, n_feats); }
+    else { AdRunner<bf16> r{*a, st, true}; rc = r.forward(*x, feats, n_feats); if (!rc && a->train_ready) rc = r.backward(feats, n_feats); }
     a->arena.dry = false;
     if (rc) return rc;
+    if (a->arena.peak + 4096 > a->arena.buf.bytes) MRISR_CHECK_HIP(hipStreamSynchronize(st));  // the old buffer may still be in use
     TRY(a->arena.buf.reserve(a->arena.peak + 4096, false));
-    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, false}; return r.forward(*x, feats, n_feats); }
+    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, false}; rc = r.forward(*x, feats, n_feats); }
+    else { AdRunner<bf16> r{*a, st, false}; rc = r.forward(*x, feats, n_feats); }
+    a->recorded = rc == 0;
+    return rc;
+    API_END
+}
+
+// ---- T2I-Adapter training: flat f32 trainable / gradient vectors owned by the caller (as for the LoRA adapters) ----
+int mrisr_adapter_train_prepare(mrisr_adapter* a, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(a && a->finalized, "adapter not finalized");
+    if (a->train_ready) return 0;
+    a->trainables.clear();
+    long long off = 0;
+    const size_t es = a->cfg.compute_dtype == MRISR_F32 ? 4 : 2;
+    for (ConvW* c : a->all_convs()) {
+        MRISR_REQUIRE(c->ks == 1 || c->ks == 3, "adapter conv kernel size");
+        c->offW = off;
+        a->trainables.push_back({c->name + ".weight", off, (long long)c->cout * c->cin * c->ks * c->ks, {c->cout, c->cin, c->ks, c->ks}});
+        off += (long long)c->cout * c->cin * c->ks * c->ks;
+        if (c->b) {
+            c->offB = off;
+            a->trainables.push_back({c->name + ".bias", off, c->cout, {c->cout}});
+            off += c->cout;
+        }
+        a->packed.emplace_back(new DevBuf());
+        TRY(a->packed.back()->reserve((size_t)c->cout * c->cin * c->ks * c->ks * es, false));
+        c->wd = a->packed.back()->p;
+    }
+    a->n_trainable = off;
+    a->train_ready = true;
+    (void)stream;
+    return 0;
+    API_END
+}
+int64_t mrisr_adapter_train_num_trainable(const mrisr_adapter* a) { return a && a->train_ready ? (int64_t)a->n_trainable : -1; }
+int mrisr_adapter_train_num_tensors(const mrisr_adapter* a) { return a && a->train_ready ? (int)a->trainables.size() : -1; }
+int mrisr_adapter_train_tensor_info(const mrisr_adapter* a, int i, const char** key, int64_t* offset, int64_t shape[4], int* ndim) {
+    MRISR_REQUIRE(a && a->train_ready && i >= 0 && i < (int)a->trainables.size() && key && offset && shape && ndim, "adapter trainable index");
+    const AdTrainable& t = a->trainables[i];
+    *key = t.key.c_str();
+    *offset = t.offset;
+    *ndim = (int)t.shape.size();
+    for (size_t k = 0; k < t.shape.size(); ++k) shape[k] = t.shape[k];
+    return 0;
+}
+int mrisr_adapter_train_refresh(mrisr_adapter* a, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(a && a->train_ready && a->theta, "bind the adapter's trainable vector first");
+    return a->cfg.compute_dtype == MRISR_F32 ? adapter_repack_t<float>(*a, (hipStream_t)stream) : adapter_repack_t<bf16>(*a, (hipStream_t)stream);
+    API_END
+}
+int mrisr_adapter_train_bind(mrisr_adapter* a, float* theta_dev, float* grad_dev, int init_from_model, void* stream) {
+    API_BEGIN
+    TRY(mrisr_adapter_train_prepare(a, stream));
+    MRISR_REQUIRE(theta_dev && grad_dev, "theta / grad device buffers");
+    a->theta = theta_dev;
+    a->grad = grad_dev;
+    if (init_from_model)
+        for (auto& t : a->trainables) {
+            auto it = a->raw.find(t.key);
+            MRISR_REQUIRE(it != a->raw.end() && it->second.numel() == t.numel, "adapter tensor missing from the loaded parameters");
+            MRISR_CHECK_HIP(hipMemcpyAsync(theta_dev + t.offset, it->second.data->p, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        }
+    return mrisr_adapter_train_refresh(a, stream);
+    API_END
+}
+int mrisr_adapter_backward(mrisr_adapter* a, const mrisr_tensor* d_feats, int n_feats, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(a && d_feats && a->train_ready && a->grad, "bind the adapter's trainable vector first");
+    hipStream_t st = (hipStream_t)stream;
+    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, false}; return r.backward(d_feats, n_feats); }
     AdRunner<bf16> r{*a, st, false};
-    return r.forward(*x, feats, n_feats);
+    return r.backward(d_feats, n_feats);
     API_END
 }
 
@@ -915,6 +1147,11 @@ int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_ten
     MRISR_REQUIRE(m, "null handle");
     return m->train_step(sample, timestep, ehs, intrablock, n_intrablock, target, loss_dev, pred_out, (hipStream_t)stream);
     API_END
+}
+int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, int n) {
+    MRISR_REQUIRE(m && n >= 0 && n <= 4 && (n == 0 || grads), "feature-gradient outputs: 0..4 tensors");
+    m->d_intra.assign(grads, grads + n);
+    return 0;
 }
 int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream) {
     MRISR_REQUIRE(g_dev && out_dev && n >= 0, "sumsq arguments");

@@ -202,6 +202,13 @@ size_t lora_wgrad_scratch_bytes(int M, int C, int nq, int elem_size);
 template <typename T> int launch_sumpool2(const void* src, void* dst, int B, int H, int W, int C, int accumulate, hipStream_t st);
 template <typename T>
 int launch_mse_grad(const void* pred, const float* tgt, void* dpred, float* loss, int B, int C, int H, int W, hipStream_t st);
+template <typename T>
+int launch_im2col_tap_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ky, int kx,
+                        int Mpad, hipStream_t st);
+template <typename T> int launch_relu_bwd(const void* dy, const void* h, void* out, long long n, hipStream_t st);
+template <typename T> int launch_colsum(const void* dy, float* out, int M, int C, hipStream_t st);
+int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st);
+template <typename T> int launch_pack_conv_dgrad(const float* w, void* wd, int Cout, int Cin, hipStream_t st);
 int launch_sumsq(const float* g, long long n, float* out, hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float grad_scale, float max_norm,
                  float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st);

@@ -96,6 +96,7 @@ struct Model {
     float* theta = nullptr;              // caller-owned flat f32 parameter vector (bound)
     float* grad = nullptr;               // caller-owned flat f32 gradient vector (bound)
     bool train_ready = false;
+    std::vector<mrisr_tensor> d_intra;   // optional outputs: gradients w.r.t. the T2I-Adapter features of the next train_step
     std::string train_ws_key;
     std::vector<LinW*> lora_linears();   // every LinW that carries adapters, fixed order
     int train_prepare(hipStream_t st);   // dgrad weight copies + trainable layout (after finalize)

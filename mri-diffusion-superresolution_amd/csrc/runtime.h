@@ -71,7 +71,8 @@ struct ConvW {  // packed [cout][ks*ks*cin] in compute dtype, bias f32
     const float* b = nullptr;
     int cin = 0, cout = 0, ks = 3;
     std::string name;    // state-dict module name (the dgrad packer re-reads the raw f32 weight)
-    void* wd = nullptr;  // training: dgrad filter bank [cin][ky'][kx'][cout] (taps flipped), compute dtype
+    void* wd = nullptr;  // training: dgrad filter bank [cin][ky'][kx'][cout] (taps flipped; 1x1: W^T [cin][cout]), compute dtype
+    long long offW = -1, offB = -1;  // training (T2I-Adapter): offsets of weight / bias in the flat trainable vector
 };
 struct LinW {  // packed [n][k] in compute dtype, bias f32 (GEGLU: interleaved)
     void* w = nullptr;

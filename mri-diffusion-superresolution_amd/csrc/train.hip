@@ -633,6 +633,22 @@ struct Trainer : Runner<T> {
         return rc;
     }
 
+    // x = x + feature (T2I-Adapter): when the backward reaches this point every consumer of x has contributed, so d(x) is
+    // also d(feature); hand it to the caller's tensor (mrisr_train_set_intrablock_grads) for the adapter's own backward
+    int export_feature_grad(const Act& x, int ib) {
+        if (ib >= (int)m.d_intra.size() || !m.d_intra[ib].data) return 0;
+        MRISR_REQUIRE(is_live(x), "adapter feature enters before any trainable block");
+        const mrisr_tensor out = m.d_intra[ib];
+        tape.push_back([=]() -> int {
+            auto it = slots.find(x.p);
+            MRISR_REQUIRE(it != slots.end() && it->second.written, "feature position has no gradient");
+            Act gx = x;
+            gx.p = it->second.g;
+            return R::export_act(gx, out, 1.0f);
+        });
+        return 0;
+    }
+
     // dst.grad (+)= src.grad   (y = copy(x) [+ constant])
     int pass_grad(const Act& y, const Act& x) {
         if (!is_live(x)) return 0;
@@ -674,7 +690,10 @@ struct Trainer : Runner<T> {
                 if (has_attn) {
                     TRY(transformer_t(lv.xf[j], x, &y));
                     x = y;
-                    if (j + 1 == lv.res.size() && ib < n_intra) TRY(R::add_external(x, intrablock[ib++]));  // + constant
+                    if (j + 1 == lv.res.size() && ib < n_intra) {
+                        TRY(R::add_external(x, intrablock[ib]));  // x += feature: d(feature) = d(x)
+                        TRY(export_feature_grad(x, ib++));
+                    }
                 }
                 skips.push_back(x);
             }
@@ -704,7 +723,8 @@ struct Trainer : Runner<T> {
                 if (!dry) MRISR_CHECK_HIP(hipMemcpyAsync(y.p, x.p, x.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
                 TRY(pass_grad(y, x));
                 x = y;
-                TRY(R::add_external(x, intrablock[ib++]));
+                TRY(R::add_external(x, intrablock[ib]));
+                TRY(export_feature_grad(x, ib++));
             }
         }
         // ---- mid ----

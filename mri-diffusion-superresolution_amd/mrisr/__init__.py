@@ -10,3 +10,4 @@ from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
 from .train import LoRATrainer, cosine_lr  # noqa: F401
 from .vae import AutoencoderKL, VAEConfig, vae_param_shapes  # noqa: F401
 from .metrics import MRIEvaluator  # noqa: F401
+from .train import AdapterTrainer, joint_step  # noqa: F401

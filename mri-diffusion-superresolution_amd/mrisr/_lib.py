@@ -58,11 +58,13 @@ EXPORTS = [
     "mrisr_model_skip_shape", "mrisr_controlnet_forward", "mrisr_controlnet_set_cond", "mrisr_adapter_create",
     "mrisr_adapter_destroy", "mrisr_adapter_set_param", "mrisr_adapter_finalize", "mrisr_adapter_forward",
     "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range",
+    "mrisr_adapter_train_prepare", "mrisr_adapter_train_num_trainable", "mrisr_adapter_train_num_tensors",
+    "mrisr_adapter_train_tensor_info", "mrisr_adapter_train_bind", "mrisr_adapter_train_refresh", "mrisr_adapter_backward",
     "mrisr_vae_create", "mrisr_vae_destroy", "mrisr_vae_set_param", "mrisr_vae_num_params", "mrisr_vae_finalize",
     "mrisr_vae_encode", "mrisr_vae_decode",
     "mrisr_image_metrics",
     "mrisr_train_prepare", "mrisr_train_num_trainable", "mrisr_train_num_tensors", "mrisr_train_tensor_info",
-    "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_optim_sumsq", "mrisr_optim_adamw",
+    "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_train_set_intrablock_grads", "mrisr_optim_sumsq", "mrisr_optim_adamw",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
     "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
     "mrisr_op_attention_bwd",

@@ -31,7 +31,56 @@ def cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int) ->
     return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * min(1.0, p))))
 
 
-class LoRATrainer:
+class _FlatAdamW:
+    """clip_grad_norm_ + AdamW on one flat f32 parameter / gradient vector pair (device kernels mrisr_optim_*)."""
+
+    def _init_flat(self, n: int, dev, lr, betas, weight_decay, eps, max_grad_norm, process_group):
+        self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
+        self.group = process_group
+        self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    @property
+    def num_trainable(self) -> int:
+        return self.theta.numel()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def all_reduce_grads(self) -> int:
+        """The data-parallel exchange step: SUM over ranks of the flat gradient bucket; returns the world size."""
+        return all_reduce_sum_(self.grad, self.group)
+
+    def sumsq(self) -> torch.Tensor:
+        """Squared L2 norm of the (reduced) gradient bucket, on the device."""
+        self._sumsq.zero_()
+        L.check(L.lib().mrisr_optim_sumsq(C.c_void_p(self.grad.data_ptr()), C.c_int64(self.grad.numel()),
+                                          C.c_void_p(self._sumsq.data_ptr()), L.stream_ptr()))
+        return self._sumsq
+
+    def _adamw(self, world: int, lr: Optional[float], sumsq: Optional[torch.Tensor] = None):
+        """``sumsq``: squared norm to clip against (default: this bucket's own; pass the sum over several buckets to clip
+        them jointly, as one ``clip_grad_norm_`` over all trainable parameters does)."""
+        self.step_count += 1
+        ss = self.sumsq() if sumsq is None else sumsq
+        L.check(L.lib().mrisr_optim_adamw(C.c_void_p(self.theta.data_ptr()), C.c_void_p(self.grad.data_ptr()),
+                                          C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                          C.c_int64(self.theta.numel()), C.c_void_p(ss.data_ptr()), C.c_float(1.0 / world),
+                                          C.c_float(self.max_grad_norm or 0.0), C.c_float(self.lr if lr is None else lr),
+                                          C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                          C.c_float(self.weight_decay), C.c_int(self.step_count), L.stream_ptr()))
+        self._last_sumsq = ss
+
+    def grad_norm(self, world: int = 1) -> float:
+        """Global L2 norm of the (averaged) gradient as used by the last ``optimizer_step``."""
+        return float(self._last_sumsq.sqrt().item()) / world
+
+
+class LoRATrainer(_FlatAdamW):
     """Owns the flat trainable / gradient / AdamW-moment vectors of a ``UNet2DConditionModel`` created with
     ``lora_rank > 0, lora_fused=True`` and drives one optimisation step."""
 
@@ -40,8 +89,6 @@ class LoRATrainer:
         if not getattr(unet, "_finalized", False):
             raise L.MrisrError("load_state_dict() first")
         self.unet = unet
-        self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
-        self.group = process_group
         lib = L.lib()
         lib.mrisr_train_num_trainable.restype = C.c_int64
         lib.mrisr_train_num_trainable.argtypes = [C.c_void_p]
@@ -49,11 +96,7 @@ class LoRATrainer:
         L.check(lib.mrisr_train_prepare(unet._h, L.stream_ptr()))
         n = int(lib.mrisr_train_num_trainable(unet._h))
         dev = unet.device
-        self.theta = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._init_flat(n, dev, lr, betas, weight_decay, eps, max_grad_norm, process_group)
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.layout: List[Tuple[str, int, Tuple[int, int]]] = []
         for i in range(int(lib.mrisr_train_num_tensors(unet._h))):
@@ -62,13 +105,8 @@ class LoRATrainer:
             self.layout.append((key.value.decode(), int(off.value), (int(shp[0]), int(shp[1]))))
         L.check(lib.mrisr_train_bind(unet._h, C.c_void_p(self.theta.data_ptr()), C.c_void_p(self.grad.data_ptr()), 1,
                                      L.stream_ptr()))
-        self.step_count = 0
 
     # ---- views ----
-    @property
-    def num_trainable(self) -> int:
-        return self.theta.numel()
-
     def _views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {k: flat[o:o + r * c].view(r, c) for k, o, (r, c) in self.layout}
 
@@ -87,12 +125,9 @@ class LoRATrainer:
         L.check(L.lib().mrisr_train_refresh(self.unet._h, L.stream_ptr()))
 
     # ---- the step, in the reference's order ----
-    def zero_grad(self):
-        self.grad.zero_()
-
     def forward_backward(self, noisy_latents: torch.Tensor, timesteps, encoder_hidden_states: torch.Tensor,
                          target: torch.Tensor, down_intrablock_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
-                         return_pred: bool = False):
+                         return_pred: bool = False, feature_grads: Optional[Sequence[torch.Tensor]] = None):
         """loss = mse(unet(noisy_latents, timesteps, ehs), target); adds d(loss)/d(adapters) to ``self.grad``.
         Returns the loss as a device scalar (and eps_hat when ``return_pred``)."""
         u = self.unet
@@ -106,34 +141,19 @@ class LoRATrainer:
         pred = torch.empty((B, u.config.out_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=u.device) if return_pred else None
         t_x, t_t, t_e, t_g = L.as_tensor(x), L.as_tensor(t), L.as_tensor(ehs), L.as_tensor(tgt)
         t_p = L.as_tensor(pred) if pred is not None else None
+        # optional: d(loss)/d(adapter features), written into the caller's tensors for the adapter's own backward
+        g_arr = L.tensor_array([L.as_tensor(f) for f in (feature_grads or [])])
+        L.check(L.lib().mrisr_train_set_intrablock_grads(u._h, g_arr if feature_grads else None, len(feature_grads or [])))
         L.check(L.lib().mrisr_train_step(u._h, C.byref(t_x), C.byref(t_t), C.byref(t_e), i_arr if intra else None, len(intra),
                                          C.byref(t_g), C.c_void_p(self._loss.data_ptr()), C.byref(t_p) if t_p else None,
                                          L.stream_ptr()))
         loss = self._loss.clone()[0]
         return (loss, pred) if return_pred else loss
 
-    def all_reduce_grads(self) -> int:
-        """The data-parallel exchange step: SUM over ranks of the flat gradient bucket; returns the world size."""
-        return all_reduce_sum_(self.grad, self.group)
-
-    def optimizer_step(self, world: int = 1, lr: Optional[float] = None):
+    def optimizer_step(self, world: int = 1, lr: Optional[float] = None, sumsq: Optional[torch.Tensor] = None):
         """clip_grad_norm_(max_grad_norm) + AdamW on the (already reduced) gradients, then re-pack the adapters."""
-        self.step_count += 1
-        lib = L.lib()
-        st = L.stream_ptr()
-        n = C.c_int64(self.theta.numel())
-        self._sumsq.zero_()
-        L.check(lib.mrisr_optim_sumsq(C.c_void_p(self.grad.data_ptr()), n, C.c_void_p(self._sumsq.data_ptr()), st))
-        L.check(lib.mrisr_optim_adamw(C.c_void_p(self.theta.data_ptr()), C.c_void_p(self.grad.data_ptr()),
-                                      C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), n,
-                                      C.c_void_p(self._sumsq.data_ptr()), C.c_float(1.0 / world), C.c_float(self.max_grad_norm or 0.0),
-                                      C.c_float(self.lr if lr is None else lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]),
-                                      C.c_float(self.eps), C.c_float(self.weight_decay), C.c_int(self.step_count), st))
-        L.check(lib.mrisr_train_refresh(self.unet._h, st))
-
-    def grad_norm(self, world: int = 1) -> float:
-        """Global L2 norm of the (averaged) gradient as used by the last ``optimizer_step``."""
-        return float(self._sumsq.sqrt().item()) / world
+        self._adamw(world, lr, sumsq)
+        L.check(L.lib().mrisr_train_refresh(self.unet._h, L.stream_ptr()))
 
     def step(self, noisy_latents, timesteps, encoder_hidden_states, target, down_intrablock_additional_residuals=None,
              lr: Optional[float] = None):
@@ -142,3 +162,76 @@ class LoRATrainer:
         world = self.all_reduce_grads()
         self.optimizer_step(world, lr)
         return loss
+
+
+class AdapterTrainer(_FlatAdamW):
+    """The reference's T2I-Adapter (``Adapter_XL``, src/adapters/modules.py:114-157) as a trainable module: every conv
+    weight / bias lives in one flat f32 vector (state-dict keys and shapes via ``layout``), ``forward`` is the adapter
+    forward that also keeps what ``backward`` needs, ``backward`` consumes the feature gradients the UNet step produced."""
+
+    def __init__(self, adapter, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999), weight_decay: float = 1e-2,
+                 eps: float = 1e-8, max_grad_norm: float = 1.0, process_group=None):
+        if not getattr(adapter, "_finalized", False):
+            raise L.MrisrError("load_state_dict() first")
+        self.adapter = adapter
+        lib = L.lib()
+        lib.mrisr_adapter_train_num_trainable.restype = C.c_int64
+        lib.mrisr_adapter_train_num_trainable.argtypes = [C.c_void_p]
+        lib.mrisr_adapter_train_num_tensors.argtypes = [C.c_void_p]
+        L.check(lib.mrisr_adapter_train_prepare(adapter._h, L.stream_ptr()))
+        self._init_flat(int(lib.mrisr_adapter_train_num_trainable(adapter._h)), adapter.device, lr, betas, weight_decay, eps,
+                        max_grad_norm, process_group)
+        self.layout: List[Tuple[str, int, Tuple[int, ...]]] = []
+        for i in range(int(lib.mrisr_adapter_train_num_tensors(adapter._h))):
+            key, off, shp, nd = C.c_char_p(), C.c_int64(), (C.c_int64 * 4)(), C.c_int()
+            L.check(lib.mrisr_adapter_train_tensor_info(adapter._h, i, C.byref(key), C.byref(off), shp, C.byref(nd)))
+            self.layout.append((key.value.decode(), int(off.value), tuple(int(shp[k]) for k in range(nd.value))))
+        L.check(lib.mrisr_adapter_train_bind(adapter._h, C.c_void_p(self.theta.data_ptr()), C.c_void_p(self.grad.data_ptr()), 1,
+                                             L.stream_ptr()))
+
+    def _views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {k: flat[o:o + math.prod(s)].view(s) for k, o, s in self.layout}
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.clone() for k, v in self._views(self.theta).items()}
+
+    def gradients(self) -> Dict[str, torch.Tensor]:
+        return self._views(self.grad)
+
+    def forward(self, x: torch.Tensor):
+        """Adapter features for ``down_intrablock_additional_residuals`` (kept for ``backward``)."""
+        self._feats = self.adapter(x)
+        return self._feats
+
+    def new_feature_grads(self):
+        """Zero tensors shaped like the last features, to hand to ``LoRATrainer.forward_backward(feature_grads=...)``."""
+        return [torch.zeros_like(f) for f in self._feats]
+
+    def backward(self, feature_grads: Sequence[torch.Tensor]):
+        g = [f.to(self.adapter.device).contiguous() for f in feature_grads]
+        arr = L.tensor_array([L.as_tensor(f) for f in g])
+        L.check(L.lib().mrisr_adapter_backward(self.adapter._h, arr, len(g), L.stream_ptr()))
+
+    def optimizer_step(self, world: int = 1, lr: Optional[float] = None, sumsq: Optional[torch.Tensor] = None):
+        self._adamw(world, lr, sumsq)
+        L.check(L.lib().mrisr_adapter_train_refresh(self.adapter._h, L.stream_ptr()))
+
+
+def joint_step(lora: LoRATrainer, adapter: AdapterTrainer, noisy_latents, timesteps, encoder_hidden_states, target, adapter_input,
+               lr: Optional[float] = None):
+    """One optimisation step of BASELINE config 3: adapter forward -> UNet forward / loss / backward (LoRA gradients +
+    feature gradients) -> adapter backward -> all-reduce of both gradient buckets -> ONE global clip over all trainable
+    parameters -> AdamW on both."""
+    lora.zero_grad()
+    adapter.zero_grad()
+    feats = adapter.forward(adapter_input)
+    fg = adapter.new_feature_grads()
+    loss = lora.forward_backward(noisy_latents, timesteps, encoder_hidden_states, target, down_intrablock_additional_residuals=feats,
+                                 feature_grads=fg)
+    adapter.backward(fg)
+    world = lora.all_reduce_grads()
+    adapter.all_reduce_grads()
+    total = lora.sumsq().clone() + adapter.sumsq()   # clip_grad_norm_ over the union of both parameter sets
+    lora.optimizer_step(world, lr, sumsq=total)
+    adapter.optimizer_step(world, lr, sumsq=total)
+    return loss

@@ -197,3 +197,99 @@ def test_step_through_rccl_process_group(tiny):
     finally:
         dist.destroy_process_group()
     assert rel(got, ref) < 1e-5
+
+
+# ---- T2I-Adapter training (BASELINE config 3: the adapter is differentiated every step) ----
+def _adapter_setup(seed=131):
+    from oracle import adapter as oa
+    acfg = oa.AdapterConfig(channels=(64, 128, 256, 256), nums_rb=2, cin=192, ksize=3)
+    return acfg, oa.init_adapter_params(acfg, seed=seed)
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("bf16", 8e-2)])
+def test_adapter_gradients_match_autograd(tiny, dt, tol):
+    """d(loss)/d(every adapter conv weight and bias) and d(loss)/d(LoRA) for loss = mse(unet(x, t, ctx, adapter(cond)), eps):
+    the UNet step hands the feature gradients to the adapter's backward (dgrad convs + one pixel-contraction GEMM per tap)."""
+    import mrisr
+    from oracle import adapter as oa
+    from oracle import unet as ou
+    cfg, up, lora = tiny
+    acfg, ap = _adapter_setup()
+    B, h = 2, 8
+    x, t, ctx, tgt = make_batch(cfg, B, h, 70, L=16)
+    cond = torch.randn((B, 3, 8 * h, 8 * h), generator=torch.Generator().manual_seed(71))
+    lp = {k: v.clone().requires_grad_(True) for k, v in lora.items()}
+    app = {k: v.clone().requires_grad_(True) for k, v in ap.items()}
+    with torch.enable_grad():
+        feats = oa.adapter_forward(app, acfg, cond)
+        pred = ou.unet_forward({**up, **lp}, cfg, x, t, ctx, down_intrablock_additional_residuals=feats, lora_scale=1.0)
+        loss_ref = torch.nn.functional.mse_loss(pred, tgt)
+        loss_ref.backward()
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype=dt, lora_rank=4, lora_alpha=4, lora_fused=True)
+    net.load_state_dict({**up, **lora})
+    ad = mrisr.Adapter_XL(channels=acfg.channels, nums_rb=acfg.nums_rb, cin=acfg.cin, ksize=acfg.ksize, compute_dtype=dt)
+    ad.load_state_dict(ap)
+    ltr, atr = mrisr.LoRATrainer(net), mrisr.AdapterTrainer(ad)
+    assert atr.num_trainable == sum(v.numel() for v in ap.values()) and {k for k, _, _ in atr.layout} == set(ap)
+    for k, v in atr.state_dict().items():
+        assert torch.equal(v.cpu(), ap[k])
+    dfeats = atr.forward(cond.cuda())
+    for f, r in zip(dfeats, feats):
+        assert rel(f, r) < (1e-3 if dt == "f32" else 3e-2)
+    fg = atr.new_feature_grads()
+    loss = ltr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), down_intrablock_additional_residuals=dfeats, feature_grads=fg)
+    assert abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < tol
+    atr.backward(fg)
+    flat_ref = torch.cat([app[k].grad.reshape(-1) for k, _, _ in atr.layout])
+    assert rel(atr.grad, flat_ref) < tol, rel(atr.grad, flat_ref)
+    lflat_ref = torch.cat([lp[k].grad.reshape(-1) for k, _, _ in ltr.layout])
+    assert rel(ltr.grad, lflat_ref) < tol
+    if dt == "f32":
+        g = atr.gradients()
+        worst = max((rel(g[k], app[k].grad), k) for k in app)
+        assert worst[0] < 1e-3, worst
+
+
+def test_joint_lora_adapter_step_matches_torch(tiny):
+    """Two full config-3 steps (adapter + UNet forward, backward of both, ONE clip over the union, AdamW on both) track
+    torch.optim.AdamW + clip_grad_norm_ on the oracle."""
+    import mrisr
+    from oracle import adapter as oa
+    from oracle import unet as ou
+    cfg, up, lora = tiny
+    acfg, ap = _adapter_setup(seed=141)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+    net.load_state_dict({**up, **lora})
+    ad = mrisr.Adapter_XL(channels=acfg.channels, nums_rb=acfg.nums_rb, cin=acfg.cin, ksize=acfg.ksize, compute_dtype="f32")
+    ad.load_state_dict(ap)
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
+    ltr, atr = mrisr.LoRATrainer(net, **kw), mrisr.AdapterTrainer(ad, **kw)
+    lp = {k: v.clone().requires_grad_(True) for k, v in lora.items()}
+    app = {k: v.clone().requires_grad_(True) for k, v in ap.items()}
+    params = list(lp.values()) + list(app.values())
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    B, h = 2, 8
+    for step in range(2):
+        x, t, ctx, tgt = make_batch(cfg, B, h, 80 + step, L=16)
+        tgt = 100.0 * tgt  # clip active
+        cond = torch.randn((B, 3, 8 * h, 8 * h), generator=torch.Generator().manual_seed(90 + step))
+        with torch.enable_grad():
+            pred = ou.unet_forward({**up, **lp}, cfg, x, t, ctx, down_intrablock_additional_residuals=oa.adapter_forward(app, acfg, cond),
+                                   lora_scale=1.0)
+            loss_ref = torch.nn.functional.mse_loss(pred, tgt)
+            opt.zero_grad()
+            loss_ref.backward()
+        norm_ref = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+        opt.step()
+        loss = mrisr.joint_step(ltr, atr, x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), cond.cuda())
+        assert abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-3
+        assert norm_ref > 1.0 and abs(ltr.grad_norm() - norm_ref) / norm_ref < 1e-3
+        for sd, ref in ((ltr.state_dict(), lp), (atr.state_dict(), app)):
+            worst = max((rel(sd[k], ref[k]), k) for k in ref)
+            assert worst[0] < 1e-3, (step, worst)
+    # the updated adapter is what its forward now computes
+    cond = torch.randn((1, 3, 64, 64), generator=torch.Generator().manual_seed(99))
+    with torch.no_grad():
+        ref = oa.adapter_forward({k: v.detach() for k, v in app.items()}, acfg, cond)
+    for f, r in zip(ad(cond.cuda()), ref):
+        assert rel(f, r) < 1e-3

@@ -118,6 +118,7 @@ struct GemmArgs {
     // profiler only: algorithmic work of this launch (0 -> derived from M, N, K)
     double alg_flops = 0.0, alg_bytes = 0.0;
     int tile = 0;  // kernel configuration chosen by gemm_choose (0: let launch_gemm plan)
+    int stage_out = 1;  // row outputs leave through LDS as whole rows (set by launch_gemm; MRISR_STAGE_OUT=0/1/2)
     // LoRA rank-r update applied in the epilogue: out[m][n] += sum_q z[m][zoff(n)+q] * lb[n][q],
     //   z = x A^T (f32, from launch_lora_down), lb = (alpha/r) * B (f32); zoff(n) = (n / lora_secN) * lora_r
     const float* lora_z = nullptr;

@@ -64,7 +64,8 @@ __device__ __forceinline__ void load4<bf16>(const bf16* p, float* v) {
 
 // v: accumulated values (already summed over K) for columns n0..n0+3 (GEGLU: u values; gate in vg).
 template <typename T>
-__device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg, const float* zl = nullptr) {
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg, const float* zl = nullptr,
+                                          T* lds_dst = nullptr) {
     const float alpha = g.alpha;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.act == ACT_GEGLU) {
@@ -130,7 +131,8 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
     if (g.out_mode == OUT_NONE) {
         if (v[0] == 1.2345e30f) store4<T>(reinterpret_cast<T*>(g.out), v);  // benchmark-only: keep the math, drop the store
     } else if (g.out_mode == OUT_ROWS) {
-        store4<T>(reinterpret_cast<T*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
+        if (lds_dst) store4<T>(lds_dst, v);  // staged: the workgroup writes the tile out as whole rows afterwards
+        else store4<T>(reinterpret_cast<T*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
     } else if (g.out_mode == OUT_F32) {
         store4<float>(reinterpret_cast<float*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
     } else {  // OUT_HEADS
@@ -419,6 +421,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
 // loop VALU-issue bound: profiles/r01_pmc_*).  Rows outside the matrix / in the zero padding get an offset
 // beyond num_records: the hardware range check returns zeros, no zero page and no select.
 // =================================================================================================
+// staged epilogue: the tile sits in LDS as [BM][pitch] T; write it out row by row, 16 bytes per lane
+template <int BM, int BN>
+__device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* otile, int pitch, int m0, int n0, int z) {
+    __syncthreads();
+    constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
+    bf16* out = reinterpret_cast<bf16*>(g.out) + (size_t)z * g.o_bs;
+    for (int idx = threadIdx.x; idx < BM * CPR; idx += 256) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m >= g.M || n >= g.N) continue;
+        const bf16* src = otile + row * pitch + ch * 8;
+        bf16* dst = out + (size_t)m * g.ldo + n;
+        if (n + 8 <= g.N) {
+            *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+        } else {
+            *reinterpret_cast<bf16x4*>(dst) = *reinterpret_cast<const bf16x4*>(src);  // N % 8 == 4 tail
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -688,6 +710,12 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
         }
         return;
     }
+    // plain row outputs leave through LDS: the accumulator layout gives every lane 8 bytes of a row (32-byte runs per
+    // store instruction, lines shared between waves - TCC counters showed 1.5x the output bytes going to HBM); staged, the
+    // workgroup writes whole rows with 16-byte stores.  The stage buffers are free here (after the LORA z rows).
+    constexpr int OPITCH = BN + 8;  // elements; 16-byte aligned rows, bank-spread
+    T* otile = reinterpret_cast<T*>(smem + (LORA ? BM * 16 * 4 : 0));
+    const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && g.heads == 1 && g.stage_out;
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -696,9 +724,11 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, z, m, n, v, nullptr, LORA ? zlds + (m - m0) * 16 : nullptr);
+                epilogue4<T>(g, z, m, n, v, nullptr, LORA ? zlds + (m - m0) * 16 : nullptr,
+                             staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr);
             }
         }
+    if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, z);
 }
 
 // =================================================================================================
@@ -875,6 +905,9 @@ __global__ __launch_bounds__(256) void gemm_halo_kernel(const GemmArgs g) {
             }
         return;
     }
+    constexpr int OPITCH = BN + 8;  // staged row output, as in gemm_bl_kernel (patch + weight stages are drained)
+    T* otile = reinterpret_cast<T*>(smem);
+    const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && (size_t)BM * OPITCH * 2 <= (size_t)pit * 4096 + 2 * WSTAGE && g.stage_out > 1;
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -883,9 +916,10 @@ __global__ __launch_bounds__(256) void gemm_halo_kernel(const GemmArgs g) {
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, 0, m, n, v, nullptr);
+                epilogue4<T>(g, 0, m, n, v, nullptr, nullptr, staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr);
             }
         }
+    if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, 0);
 }
 
 // =================================================================================================
@@ -1491,6 +1525,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     MRISR_REQUIRE(zero_page() != nullptr, "zero page not initialised");
     if (g.conv) MRISR_REQUIRE(g.K == 9 * (g.c0 + g.c1), "conv K");
     else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
+    static const int stage_env = [] { const char* e = getenv("MRISR_STAGE_OUT"); return e ? atoi(e) : 1; }();  // 0 off, 1 tiled kernels, 2 + halo
+    const_cast<GemmArgs&>(g).stage_out = stage_env;
     int tile = g.tile ? g.tile : g_force_tile, s = g.splitk;
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
     if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;

@@ -1453,7 +1453,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
             g.tile = tile;
             if (launch_gemm<bf16>(g, nullptr)) return 1;  // warm-up
             MRISR_CHECK_HIP(hipEventRecord(e0, nullptr));
-            const int iters = 3;
+            static const int iters = [] { const char* e = getenv("MRISR_TUNE_ITERS"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
             for (int i = 0; i < iters; ++i) (void)launch_gemm<bf16>(g, nullptr);
             MRISR_CHECK_HIP(hipEventRecord(e1, nullptr));
             MRISR_CHECK_HIP(hipEventSynchronize(e1));

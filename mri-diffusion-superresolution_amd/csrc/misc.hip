@@ -331,10 +331,24 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const DirectConvArgs a)
                 if (ix < 0 || ix >= a.Win) continue;
                 const T* xp = x + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin;
                 const T* wr = wT + (size_t)((ky * a.ks + kx) * a.Cin) * a.Cout + cg * 8;
+                float xin[4];
+                const bool vec4 = sizeof(T) == 2 && a.Cin == 4;  // conv_in: the pixel's 4 channels in one 8-byte load
+                if constexpr (sizeof(T) == 2) {
+                    if (vec4) {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4*>(xp);
+                        xin[0] = (float)t[0]; xin[1] = (float)t[1]; xin[2] = (float)t[2]; xin[3] = (float)t[3];
+                    }
+                }
                 for (int c = 0; c < a.Cin; ++c) {
-                    const float xv = to_f32(xp[c]);
+                    const float xv = vec4 ? xin[c & 3] : to_f32(xp[c]);
+                    if constexpr (sizeof(T) == 2) {  // one 16-byte LDS read for the 8 output channels
+                        const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(wr + (size_t)c * a.Cout);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += xv * to_f32(wr[(size_t)c * a.Cout + e]);
+                        for (int e = 0; e < 8; ++e) acc[e] += xv * (float)w8[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] += xv * to_f32(wr[(size_t)c * a.Cout + e]);
+                    }
                 }
             }
         }

@@ -123,21 +123,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs a, in
     const int r_beg = blockIdx.x * rows_per_block;
     const int r_end = min(a.HW, r_beg + rows_per_block);
     T* y = reinterpret_cast<T*>(a.y) + (size_t)b * a.HW * C;
-    for (int r = r_beg + rl; r < r_end; r += RL) {
+    // UR rows per iteration: all their loads are issued before the first use (a thread otherwise has one 16-byte load in
+    // flight at a time and the pass runs at latency, not bandwidth)
+    constexpr int UR = 4;
+    for (int r0 = r_beg + rl; r0 < r_end; r0 += RL * UR) {
+        vec_t xv[UR][VPT];
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int ch = (slot * VPT + v) * VE;
-            const T* src = ch < a.c0 ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
-                                     : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
-            const vec_t x = *reinterpret_cast<const vec_t*>(src);
-            vec_t o;
+        for (int u = 0; u < UR; ++u) {
+            const int r = r0 + u * RL;
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                float f = (float)x[e] * sc[v][e] + sh[v][e];
-                if (a.silu) f = silu_f(f);
-                o[e] = from_f32<T>(f);
+            for (int v = 0; v < VPT; ++v) {
+                const int ch = (slot * VPT + v) * VE;
+                const T* src = ch < a.c0 ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                                         : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+                if (r < r_end) xv[u][v] = *reinterpret_cast<const vec_t*>(src);
             }
-            *reinterpret_cast<vec_t*>(y + (size_t)r * C + ch) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int r = r0 + u * RL;
+            if (r >= r_end) break;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int ch = (slot * VPT + v) * VE;
+                vec_t o;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    float f = (float)xv[u][v][e] * sc[v][e] + sh[v][e];
+                    if (a.silu) f = silu_f(f);
+                    o[e] = from_f32<T>(f);
+                }
+                *reinterpret_cast<vec_t*>(y + (size_t)r * C + ch) = o;
+            }
         }
     }
 }
@@ -168,8 +185,15 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     const size_t smem = (size_t)2 * RL * C * sizeof(float);
     dim3 grid(a.nsplit, a.B);
     const double act_bytes = (double)a.B * a.HW * C * sizeof(T);
+    std::string n1 = "groupnorm_stats", n2 = "groupnorm_apply";
+    if (prof_enabled() && prof_shapes()) {
+        char buf[96];
+        snprintf(buf, sizeof(buf), " B=%d HW=%d C=%d", a.B, a.HW, C);
+        n1 += buf;
+        n2 += buf;
+    }
     {
-    ProfScope ps("groupnorm_stats", 0.0, act_bytes, st);
+    ProfScope ps(prof_intern(n1), 0.0, act_bytes, st);
     switch (vpt) {
         case 1: hipLaunchKernelGGL((gn_stats_kernel<T, 1>), grid, dim3(256), smem, st, a, slots, RL); break;
         case 2: hipLaunchKernelGGL((gn_stats_kernel<T, 2>), grid, dim3(256), smem, st, a, slots, RL); break;
@@ -179,11 +203,11 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     }
     MRISR_CHECK_HIP(hipGetLastError());
     // ~2048 blocks over the batch; every block streams a contiguous run of rows
-    int bx = 2048 / (a.B > 0 ? a.B : 1) + 1;
+    int bx = 1024 / (a.B > 0 ? a.B : 1) + 1;
     int rows_per_block = (a.HW + bx - 1) / bx;
     if (rows_per_block < RL) rows_per_block = RL;
     bx = (a.HW + rows_per_block - 1) / rows_per_block;
-    ProfScope ps2("groupnorm_apply", 0.0, 2.0 * act_bytes, st);
+    ProfScope ps2(prof_intern(n2), 0.0, 2.0 * act_bytes, st);
     switch (vpt) {
         case 1: hipLaunchKernelGGL((gn_apply_kernel<T, 1>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
         case 2: hipLaunchKernelGGL((gn_apply_kernel<T, 2>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;

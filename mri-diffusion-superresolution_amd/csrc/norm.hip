@@ -39,20 +39,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormArgs a, in
 #pragma unroll
         for (int e = 0; e < VE; ++e) s1[v][e] = s2[v][e] = 0.f;
     if (rl < RL) {
-        for (int r = r_beg + rl; r < r_end; r += RL) {
+        constexpr int UR = 4;  // rows in flight per thread (the pass is otherwise latency-, not bandwidth-bound)
+        for (int r0 = r_beg + rl; r0 < r_end; r0 += RL * UR) {
+            vec_t xv[UR][VPT];
 #pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                const int ch = (slot * VPT + v) * VE;
-                const T* src = ch < a.c0
-                                   ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
-                                   : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
-                const vec_t x = *reinterpret_cast<const vec_t*>(src);
+            for (int u = 0; u < UR; ++u) {
+                const int r = r0 + u * RL;
 #pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    const float f = (float)x[e];
-                    s1[v][e] += f;
-                    s2[v][e] += f * f;
+                for (int v = 0; v < VPT; ++v) {
+                    const int ch = (slot * VPT + v) * VE;
+                    const T* src = ch < a.c0
+                                       ? reinterpret_cast<const T*>(a.x0) + ((size_t)b * a.HW + r) * a.c0 + ch
+                                       : reinterpret_cast<const T*>(a.x1) + ((size_t)b * a.HW + r) * a.c1 + (ch - a.c0);
+                    if (r < r_end) xv[u][v] = *reinterpret_cast<const vec_t*>(src);
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                if (r0 + u * RL >= r_end) break;
+#pragma unroll
+                for (int v = 0; v < VPT; ++v)
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const float f = (float)xv[u][v][e];
+                        s1[v][e] += f;
+                        s2[v][e] += f * f;
+                    }
             }
         }
 #pragma unroll

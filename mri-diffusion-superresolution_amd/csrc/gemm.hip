@@ -458,7 +458,7 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 // tile; one wave column accumulates z for its rows on the matrix cores) is computed by the workgroup itself and handed
 // to the epilogue through LDS - no separate pass over x, no z round trip through HBM.
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool LORA>
-__global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  // 2 waves / SIMD: two workgroups per CU hide each other's loads
     // Only the 2-stage form is instantiated: it synchronises with vmcnt(0), which is correct however out-of-range
     // (zero-fill) LDS-DMA instructions retire.  The counted-vmcnt ring below is kept for reference but must not be used
     // with out-of-range offsets (fully out-of-range instructions retire out of order; see gemm_big_kernel).
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void gemm_bl_kernel(const GemmArgs g) {
 // Weights stay double buffered per tap; the K order (ky, kx, cin) of the packed filter bank is unchanged.
 // =================================================================================================
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void gemm_halo_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
     typedef bf16 T;
     constexpr int BK = 64;
     constexpr int W_IT = BN / 32;

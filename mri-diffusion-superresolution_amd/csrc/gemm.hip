@@ -1182,7 +1182,7 @@ static size_t halo_smem(const GemmArgs& g, int BM, int BN) {
 // eligibility of the halo kernel for a conv launch with M tile BM
 static bool halo_ok(const GemmArgs& g, int BM) {
     if (!g.conv || g.stride != 1 || g.ups != 0 || g.zstuff || g.batch != 1 || g.pad != 1) return false;
-    if (g.Win % 16 != 0 || g.Win > 64 || BM % g.Win != 0) return false;
+    if (g.Win % 8 != 0 || g.Win > 64 || BM % g.Win != 0) return false;  // (a 16-pixel fragment may span two image rows: prow is per pixel)
     if ((g.Hin * g.Win) % BM != 0 || g.M % BM != 0 || g.Hout != g.Hin || g.Wout != g.Win) return false;
     const int npix = (BM / g.Win + 2) * (g.Win + 2);
     const int pit_max = BM >= 256 ? 13 : (BM >= 128 ? 9 : 6);

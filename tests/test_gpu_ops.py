@@ -186,7 +186,7 @@ def test_conv3x3_buffer_addressed_kernel(tile, B, Cin, Cout, H, stride, ups, spl
     (41, 2, 64, 0, 320, 32, 1), (41, 1, 320, 0, 320, 16, 1), (41, 2, 128, 64, 160, 16, 1), (41, 1, 256, 0, 64, 32, 2),
     (42, 2, 64, 0, 128, 32, 1), (42, 1, 128, 128, 320, 16, 2), (43, 3, 64, 0, 320, 16, 1), (43, 1, 128, 0, 100, 32, 1),
     (44, 1, 64, 64, 384, 32, 1), (44, 2, 192, 0, 640, 16, 1), (45, 1, 64, 0, 64, 64, 1), (45, 2, 128, 0, 320, 16, 1),
-    (41, 1, 64, 0, 160, 64, 1),
+    (41, 1, 64, 0, 160, 64, 1), (43, 4, 128, 0, 320, 8, 1), (43, 2, 64, 64, 96, 8, 2),
 ])
 def test_conv3x3_halo_kernel(tile, B, C1, C2, Cout, H, splitk):
     """The LDS-halo conv kernel (the input neighbourhood staged once per 64-channel chunk, nine taps read shifted

@@ -65,7 +65,7 @@ __device__ __forceinline__ void load4<bf16>(const bf16* p, float* v) {
 // v: accumulated values (already summed over K) for columns n0..n0+3 (GEGLU: u values; gate in vg).
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg, const float* zl = nullptr,
-                                          T* lds_dst = nullptr) {
+                                          T* lds_dst = nullptr, bool resid_later = false, bool mfma_lanes = true) {
     const float alpha = g.alpha;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.act == ACT_GEGLU) {
@@ -122,7 +122,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
     }
     const size_t zoff = (size_t)(z / g.heads) * g.o_bs + (size_t)(z % g.heads) * g.o_hs;
-    if (g.resid) {
+    if (g.resid && !resid_later) {
         float r4[4];
         load4<T>(reinterpret_cast<const T*>(g.resid) + zoff + (size_t)m * g.ldr + n0, r4);
 #pragma unroll
@@ -147,7 +147,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
         const size_t bh = (size_t)b * g.nheads + h;
         if (!tr) {
             store4<T>(base + (bh * g.npad + tok) * g.dpad + dd, v);
-        } else if (sizeof(T) == 2 && (g.ntok & 3) == 0 && (g.M & 3) == 0) {
+        } else if (sizeof(T) == 2 && mfma_lanes && (g.ntok & 3) == 0 && (g.M & 3) == 0) {
+            // (only from the MFMA kernels, where lanes fr ^ 1, fr ^ 2 hold the neighbouring tokens - NOT from the split-K
+            // reduce kernel, whose threads walk the output linearly)
             // V^T [b][h][d][token]: the lane holds 4 d-values of ONE token, so a direct store is 4 x 2 bytes at a
             // token stride.  Exchange with the 3 neighbouring token lanes (fr ^ 1, fr ^ 2) so that every lane ends up
             // with 4 consecutive tokens of ONE d row: a single 8-byte store (all lanes of the exchange are valid
@@ -423,10 +425,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
 // =================================================================================================
 // staged epilogue: the tile sits in LDS as [BM][pitch] T; write it out row by row, 16 bytes per lane
 template <int BM, int BN>
-__device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* otile, int pitch, int m0, int n0, int z) {
+__device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* otile, int pitch, int m0, int n0, int z, bool add_resid) {
     __syncthreads();
     constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
     bf16* out = reinterpret_cast<bf16*>(g.out) + (size_t)z * g.o_bs;
+    const bf16* res = add_resid ? reinterpret_cast<const bf16*>(g.resid) + (size_t)z * g.o_bs : nullptr;
     for (int idx = threadIdx.x; idx < BM * CPR; idx += 256) {
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = m0 + row, n = n0 + ch * 8;
@@ -434,9 +437,21 @@ __device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* oti
         const bf16* src = otile + row * pitch + ch * 8;
         bf16* dst = out + (size_t)m * g.ldo + n;
         if (n + 8 <= g.N) {
-            *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+            if (res) {  // residual added here, read as whole rows too (may alias dst: same thread reads then writes)
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + (size_t)m * g.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+            }
+            *reinterpret_cast<bf16x8*>(dst) = v;
         } else {
-            *reinterpret_cast<bf16x4*>(dst) = *reinterpret_cast<const bf16x4*>(src);  // N % 8 == 4 tail
+            bf16x4 v = *reinterpret_cast<const bf16x4*>(src);  // N % 8 == 4 tail
+            if (res) {
+                const bf16x4 r = *reinterpret_cast<const bf16x4*>(res + (size_t)m * g.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+            }
+            *reinterpret_cast<bf16x4*>(dst) = v;
         }
     }
 }
@@ -716,6 +731,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
     constexpr int OPITCH = BN + 8;  // elements; 16-byte aligned rows, bank-spread
     T* otile = reinterpret_cast<T*>(smem + (LORA ? BM * 16 * 4 : 0));
     const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && g.heads == 1 && g.stage_out;
+    // the residual is then added in the copy-out pass (whole-row reads; the staged value is already rounded to bf16)
+    const bool resid_later = staged && g.resid != nullptr && (g.ldr & 7) == 0 && g.stage_out < 3;
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -725,10 +742,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 epilogue4<T>(g, z, m, n, v, nullptr, LORA ? zlds + (m - m0) * 16 : nullptr,
-                             staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr);
+                             staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later);
             }
         }
-    if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, z);
+    if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, z, resid_later);
 }
 
 // =================================================================================================
@@ -908,6 +925,7 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
     constexpr int OPITCH = BN + 8;  // staged row output, as in gemm_bl_kernel (patch + weight stages are drained)
     T* otile = reinterpret_cast<T*>(smem);
     const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && (size_t)BM * OPITCH * 2 <= (size_t)pit * 4096 + 2 * WSTAGE && g.stage_out > 1;
+    const bool resid_later = staged && g.resid != nullptr && (g.ldr & 7) == 0 && g.stage_out < 3;
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -916,10 +934,10 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, 0, m, n, v, nullptr, nullptr, staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr);
+                epilogue4<T>(g, 0, m, n, v, nullptr, nullptr, staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later);
             }
         }
-    if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, 0);
+    if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, 0, resid_later);
 }
 
 // =================================================================================================
@@ -1049,7 +1067,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += t[r];
         }
-        epilogue4<T>(g, z, m, n, v, nullptr);
+        epilogue4<T>(g, z, m, n, v, nullptr, nullptr, nullptr, false, /*mfma_lanes=*/false);
     }
 }
 
@@ -1438,6 +1456,10 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
+        {   // debugging aid: MRISR_TUNE_SKIP="41,43" removes candidates
+            static const std::string skip = [] { const char* e = getenv("MRISR_TUNE_SKIP"); return std::string(e ? e : ""); }();
+            if (!skip.empty() && ("," + skip + ",").find("," + std::to_string(tile) + ",") != std::string::npos) continue;
+        }
         if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
         if (tile >= 50 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
         // 5 fragments per wave along N (BN = 160): no (u, gate) pairing for the GEGLU epilogue
@@ -1483,6 +1505,8 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
 }
 
 // Chooses tile + split-K for g (sets g.tile / g.splitk).  Deterministic per signature within a process.
+static int g_force_split = 0;  // test hook: split-K factor for every GEMM that can be split (exercises the reduce kernel's epilogue)
+extern "C" void mrisr_debug_force_split(int s) { g_force_split = s; }
 static int g_prefer_tile = 0;  // test hook: use this specialised kernel (halo 41-45 / weight-stationary 50-52) wherever it is eligible
 extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
 
@@ -1502,6 +1526,10 @@ int gemm_choose(GemmArgs& g, bool is_bf16) {
         plan(g, is_bf16, 0, &t, &s);
     }
     (void)cs;
+    if (g_force_split > 1 && g.act != ACT_GEGLU && g.K / (is_bf16 ? 64 : 32) >= g_force_split && !g.lora_a) {
+        s = g_force_split;
+        if (t >= 50) t = is_bf16 ? 14 : 1;
+    }
     g.tile = t;
     g.splitk = s;
     return 0;
@@ -1525,7 +1553,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     MRISR_REQUIRE(zero_page() != nullptr, "zero page not initialised");
     if (g.conv) MRISR_REQUIRE(g.K == 9 * (g.c0 + g.c1), "conv K");
     else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
-    static const int stage_env = [] { const char* e = getenv("MRISR_STAGE_OUT"); return e ? atoi(e) : 1; }();  // 0 off, 1 tiled kernels, 2 + halo
+    static const int stage_env = [] { const char* e = getenv("MRISR_STAGE_OUT"); return e ? atoi(e) : 2; }();  // 0 off, 1 tiled kernels, 2 + halo kernels (default), 3: as 2 but residual added before staging
     const_cast<GemmArgs&>(g).stage_out = stage_env;
     int tile = g.tile ? g.tile : g_force_tile, s = g.splitk;
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);

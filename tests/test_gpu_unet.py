@@ -59,6 +59,34 @@ def test_unet_forward_matches_oracle(tiny, dt, tol, lora_fused):
 
 
 @pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("bf16", 5e-2)])
+def test_unet_with_every_gemm_split(tiny, dt, tol):
+    """Split-K forced on every GEMM that can be split: the reduce kernel then runs every epilogue variant (bias, time
+    embedding, residual in place, LoRA rank tail, head-major Q/K scatter and the transposed V^T store - the latter once
+    used a lane exchange that is only valid in the MFMA kernels' lane layout)."""
+    import ctypes as C
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg, up, lora, _ = tiny
+    p = {**up, **lora}
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, cfg.cross_attention_dim), generator=g)
+    t = torch.tensor([3, 600])
+    ref = ou.unet_forward(p, cfg, x, t, ctx)
+    lib = L.lib()
+    try:
+        for split in (2, 4):
+            lib.mrisr_debug_force_split(C.c_int(split))
+            net = mrisr.UNet2DConditionModel(cfg, compute_dtype=dt, lora_rank=4, lora_alpha=4)
+            net.load_state_dict(p)
+            out = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+            assert rel(out, ref) < tol, (dt, split, rel(out, ref))
+    finally:
+        lib.mrisr_debug_force_split(C.c_int(0))
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("bf16", 5e-2)])
 def test_unet_materialised_attention_path(tiny, dt, tol):
     import mrisr
     from oracle import unet as ou

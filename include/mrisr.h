@@ -217,6 +217,8 @@ int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_ten
  * grads[i] (same shapes; NCHW f32/bf16 or NHWC compute dtype) for the adapter's own backward; n = 0 switches it off. */
 int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, int n);
 int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream);
+/* ema = decay * ema + (1 - decay) * theta  (diffusers EMAModel.step on the flat trainable vector) */
+int mrisr_optim_ema(float* ema_dev, const float* theta_dev, int64_t n, float decay, void* stream);
 int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, const float* sumsq_dev,
                       float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int step, void* stream);

@@ -947,6 +947,16 @@ int launch_pack_conv_dgrad(const float* w, void* wd, int Cout, int Cin, hipStrea
     return 0;
 }
 
+// exponential moving average of the trainable vector (diffusers EMAModel.step): ema = decay * ema + (1 - decay) * theta
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ theta, long long n, float decay) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) ema[i] = decay * ema[i] + (1.f - decay) * theta[i];
+}
+int launch_ema(float* ema, const float* theta, long long n, float decay, hipStream_t st) {
+    hipLaunchKernelGGL(ema_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, ema, theta, n, decay);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 #define BWD_INST(T)                                                                                                         \
     template int launch_groupnorm_bwd<T>(const GroupNormBwdArgs&, hipStream_t);                                             \
     template int launch_layernorm_bwd<T>(const void*, const void*, void*, const float*, int, int, float, int, hipStream_t); \

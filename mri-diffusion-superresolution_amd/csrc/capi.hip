@@ -1157,6 +1157,10 @@ int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* strea
     MRISR_REQUIRE(g_dev && out_dev && n >= 0, "sumsq arguments");
     return launch_sumsq(g_dev, (long long)n, out_dev, (hipStream_t)stream);
 }
+int mrisr_optim_ema(float* ema_dev, const float* theta_dev, int64_t n, float decay, void* stream) {
+    MRISR_REQUIRE(ema_dev && theta_dev && n >= 0 && decay >= 0.f && decay <= 1.f, "ema arguments");
+    return launch_ema(ema_dev, theta_dev, (long long)n, decay, (hipStream_t)stream);
+}
 int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, const float* sumsq_dev,
                       float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int step, void* stream) {

@@ -211,6 +211,7 @@ template <typename T> int launch_colsum(const void* dy, float* out, int M, int C
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st);
 template <typename T> int launch_pack_conv_dgrad(const float* w, void* wd, int Cout, int Cin, hipStream_t st);
 int launch_sumsq(const float* g, long long n, float* out, hipStream_t st);
+int launch_ema(float* ema, const float* theta, long long n, float decay, hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float grad_scale, float max_norm,
                  float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st);
 

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -74,6 +75,33 @@ class _FlatAdamW:
                                           C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                           C.c_float(self.weight_decay), C.c_int(self.step_count), L.stream_ptr()))
         self._last_sumsq = ss
+
+    # ---- EMA of the trainable parameters (diffusers EMAModel: use_ema in the reference's training config) ----
+    def ema_step(self, decay: float = 0.9999):
+        if getattr(self, "ema", None) is None:
+            self.ema = self.theta.clone()
+            return
+        L.check(L.lib().mrisr_optim_ema(C.c_void_p(self.ema.data_ptr()), C.c_void_p(self.theta.data_ptr()), C.c_int64(self.theta.numel()),
+                                        C.c_float(decay), L.stream_ptr()))
+
+    # ---- checkpoints: parameters under their state-dict keys (safetensors, loadable by peft / the reference module), the
+    #      optimiser state as flat vectors ----
+    def save_checkpoint(self, path: str, use_ema: bool = False):
+        from safetensors.torch import save_file
+        flat = self.ema if (use_ema and getattr(self, "ema", None) is not None) else self.theta
+        save_file({k: v.contiguous().cpu() for k, v in self._views(flat).items()}, path)
+        torch.save({"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
+                    "ema": None if getattr(self, "ema", None) is None else self.ema.cpu()}, path + ".optim.pt")
+
+    def load_checkpoint(self, path: str):
+        from safetensors.torch import load_file
+        self.load_state_dict(load_file(path))
+        if os.path.exists(path + ".optim.pt"):
+            st = torch.load(path + ".optim.pt", map_location="cpu")
+            self.step_count = int(st["step"])
+            self.exp_avg.copy_(st["exp_avg"])
+            self.exp_avg_sq.copy_(st["exp_avg_sq"])
+            self.ema = None if st["ema"] is None else st["ema"].to(self.theta.device)
 
     def grad_norm(self, world: int = 1) -> float:
         """Global L2 norm of the (averaged) gradient as used by the last ``optimizer_step``."""
@@ -197,6 +225,13 @@ class AdapterTrainer(_FlatAdamW):
 
     def gradients(self) -> Dict[str, torch.Tensor]:
         return self._views(self.grad)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        views = self._views(self.theta)
+        for k, v in sd.items():
+            if k in views:
+                views[k].copy_(v.to(self.theta.device, torch.float32))
+        L.check(L.lib().mrisr_adapter_train_refresh(self.adapter._h, L.stream_ptr()))
 
     def forward(self, x: torch.Tensor):
         """Adapter features for ``down_intrablock_additional_residuals`` (kept for ``backward``)."""

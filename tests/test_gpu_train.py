@@ -293,3 +293,36 @@ def test_joint_lora_adapter_step_matches_torch(tiny):
         ref = oa.adapter_forward({k: v.detach() for k, v in app.items()}, acfg, cond)
     for f, r in zip(ad(cond.cuda()), ref):
         assert rel(f, r) < 1e-3
+
+
+def test_ema_and_checkpoint_roundtrip(tiny, tmp_path):
+    """EMA of the adapters (diffusers EMAModel.step) and checkpoint interchange: parameters as safetensors under their peft
+    keys, optimiser moments alongside; a restored trainer continues bit-identically."""
+    import mrisr
+    from safetensors.torch import load_file
+    cfg, up, lora = tiny
+    x, t, ctx, tgt = make_batch(cfg, 2, 8, 120, L=16)
+
+    def fresh():
+        net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+        net.load_state_dict({**up, **lora})
+        return mrisr.LoRATrainer(net, lr=1e-3)
+
+    tr = fresh()
+    tr.ema_step(0.9)                       # first call seeds the average with the parameters
+    tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    theta0 = torch.cat([lora[k].reshape(-1) for k, _, _ in tr.layout]).cuda()
+    tr.ema_step(0.9)
+    assert rel(tr.ema, 0.9 * theta0 + 0.1 * tr.theta) < 1e-6
+    path = str(tmp_path / "lora.safetensors")
+    tr.save_checkpoint(path)
+    sd = load_file(path)
+    assert set(sd) == set(lora) and all(torch.equal(sd[k], tr.state_dict()[k].cpu()) for k in sd)
+    tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    tr2 = fresh()
+    tr2.load_checkpoint(path)
+    assert tr2.step_count == 1
+    tr2.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    assert rel(tr2.theta, tr.theta) < 1e-6
+    tr.save_checkpoint(str(tmp_path / "ema.safetensors"), use_ema=True)
+    assert rel(torch.cat([load_file(str(tmp_path / "ema.safetensors"))[k].reshape(-1) for k, _, _ in tr.layout]), tr.ema) < 1e-7

@@ -465,19 +465,13 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 }
 #define BL_OOB 0x80000000u
 
-// NSTAGE = 2: double buffer, one drain + barrier per K tile - best when >= 2 workgroups share a CU and hide each
-// other's load latency.  NSTAGE > 2: an LDS ring with NSTAGE-1 tiles of LDS-DMA in flight behind a counted
-// `s_waitcnt vmcnt(N)` and a raw `s_barrier` - for shapes with too few tiles to give every CU two workgroups
-// (small M / deep K), where the 2-stage loop is bound by one exposed load latency per K tile.
-// LORA: the adapter's down-projection z = x A^T (R <= 16 rows of A ride along as 16 extra "weight" rows of every K
-// tile; one wave column accumulates z for its rows on the matrix cores) is computed by the workgroup itself and handed
-// to the epilogue through LDS - no separate pass over x, no z round trip through HBM.
+// NSTAGE = 2: double buffer, one drain (vmcnt(0)) + barrier per K tile; two workgroups share a CU and hide each other's
+// load latency.  Deeper rings with a counted vmcnt were tried twice (8-wave kernels, and 3-stage 4-wave variants on
+// in-range shapes) and lost every time (profiles/r01_gemm_sweep_incl_deep_stages.log, profiles/r01b_ws_sweep.log); note that
+// a fully out-of-range LDS-DMA instruction retires out of order, so a counted wait is only safe without padding rows.
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool LORA>
 __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  // 2 waves / SIMD: two workgroups per CU hide each other's loads
-    // Only the 2-stage form is instantiated: it synchronises with vmcnt(0), which is correct however out-of-range
-    // (zero-fill) LDS-DMA instructions retire.  The counted-vmcnt ring below is kept for reference but must not be used
-    // with out-of-range offsets (fully out-of-range instructions retire out of order; see gemm_big_kernel).
-    static_assert(NSTAGE == 2, "ring form disabled: unsafe with out-of-range LDS-DMA");
+    static_assert(NSTAGE == 2, "double buffer only (see the note above)");
     typedef bf16 T;
     constexpr int BK = 64;
     constexpr int A_IT = BM / 32, W_IT = BN / 32;
@@ -577,15 +571,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
     auto stage = [&](int kt, int buf) {
         char* sb = smem + buf * STAGE;
         const unsigned k0b = (unsigned)kt * BK * 2;
-        if (NSTAGE > 2 && kt >= kt_end) {
-            // past the end of this split: keep every wave's DMA count constant (the counted vmcnt depends on it);
-            // out-of-range offsets are dropped to zeros by the descriptor's range check
-#pragma unroll
-            for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, BL_OOB, 0);
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) bl16(ra0, sb + (it * 256 + wave * 64) * 16, BL_OOB, 0);
-            return;
-        }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, wvo[it], k0b);
         if (LORA && wave < 2) bl16(rl, sb + (BM + BN) * 128 + wave * 64 * 16, lvo, k0b);

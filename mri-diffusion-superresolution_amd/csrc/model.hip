@@ -101,14 +101,14 @@ struct Packer {
         const bool fused_lora = m.cfg.lora_rank > 0 && m.cfg.lora_fused;
         int ntot = 0, k = 0;
         bool any_lora = false;
-        int rsum = 0, rmod = 0, nmod0 = 0;
+        int rmod = 0, nmod0 = 0;
         for (auto& mod : mods) {
             const RawParam* w = need(mod + ".weight");
             if (!w) return l;
             ntot += (int)w->shape[0];
             k = (int)w->shape[1];
             const RawParam* la = m.find(mod + ".lora_A.default.weight");
-            if (la) { any_lora = true; rsum += (int)la->shape[0]; rmod = (int)la->shape[0]; }
+            if (la) { any_lora = true; rmod = (int)la->shape[0]; }
             if (!nmod0) nmod0 = (int)w->shape[0];
         }
         l.n = ntot;

@@ -23,6 +23,7 @@
  */
 #ifndef MRISR_H
 #define MRISR_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -130,7 +131,11 @@ int mrisr_resshift_forward(const mrisr_tensor* hr, const mrisr_tensor* lr, const
                            void* stream);
 
 /* ---- sampler: the timestep loop, one hipGraph per step -------------------------------------------- */
-typedef enum { MRISR_STEP_DDIM = 0, MRISR_STEP_RESSHIFT = 1 } mrisr_step_kind;
+/* MRISR_STEP_DDPM: the ancestral step of diffusers' DDPMScheduler.step ("fixed_small" variance; BASELINE config 1, "10-step
+ * DDPM"): t_prev = t - T/n, alpha_t = abar_t / abar_prev, x0 = (x - sqrt(1-abar_t) eps) / sqrt(abar_t) [clipped to
+ * +-clip_sample_range when set], x_prev = sqrt(abar_prev) (1-alpha_t)/(1-abar_t) x0 + sqrt(alpha_t) (1-abar_prev)/(1-abar_t) x
+ * + sqrt((1-abar_prev)/(1-abar_t) (1-alpha_t)) z for t > 0;  z = step_noise slab i (NULL: the mean only). */
+typedef enum { MRISR_STEP_DDIM = 0, MRISR_STEP_RESSHIFT = 1, MRISR_STEP_DDPM = 2 } mrisr_step_kind;
 /* timesteps: host int64[n_steps]; alphas_cumprod: host f32[n_train]; unet required, controlnet may be NULL. */
 int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_kind, const int64_t* timesteps,
                          int n_steps, const float* alphas_cumprod, int n_train, mrisr_sampler** out);
@@ -146,6 +151,9 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
 /* Restrict the next runs to steps [first_step, last_step) of the schedule (default: all).  Step i always uses the
  * schedule's own (t_i, t_{i+1}) pair, so a truncated run reproduces the prefix of the full trajectory. */
 int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step);
+/* DDPM only: clip the predicted x0 to [-range, range] (diffusers clip_sample / clip_sample_range); range <= 0 disables
+ * (the default, as in the SD-1.5 scheduler config). */
+int mrisr_sampler_set_clip(mrisr_sampler* s, float clip_sample_range);
 
 /* ---- T2I-Adapter training (in BASELINE config 3 the adapter runs, and is differentiated, every step)
  * Same ownership model as the LoRA step: the caller owns ONE flat f32 vector of all adapter parameters (PyTorch layouts,
@@ -230,6 +238,22 @@ int mrisr_optim_adamw(float* p_dev, const float* g_dev, float* m_dev, float* v_d
  * scratch: 2*batch*height*width floats; sums: batch*6 doubles (zeroed here). */
 int mrisr_image_metrics(const float* pred_dev, const float* gt_dev, int batch, int height, int width, float* scratch_dev,
                         double* sums_dev, float* out_dev, void* stream);
+
+/* ---- slice degradation of the reference's data pipeline (nb ResDif c22:102-154) ----------------
+ * All images are f32 [batch][height][width] on the device.  scratch sizes come from the *_scratch_bytes functions.
+ *   resize_slices:        Pillow Image.resize on mode "F" (filter 0 = BICUBIC a=-0.5, 1 = LANCZOS a=3; antialiased support when
+ *                         shrinking) - replaces FastMRILazyDataset._pad_to_target's resize            nb ResDif c22:102-113
+ *   gaussian_blur_slices: scipy.ndimage.gaussian_filter(sigma, mode "reflect", truncate)               nb ResDif c22:143-144
+ *   simulate_low_field:   blur(sigma 0.5*scale) -> BICUBIC to the small size -> BICUBIC back            nb ResDif c22:140-154
+ *                         (small size = (W//scale) rows x (H//scale) columns, the reference's own tuple order) */
+size_t mrisr_resize_scratch_bytes(int batch, int height, int width, int out_height, int out_width, int filter);
+int mrisr_resize_slices(const float* in_dev, int batch, int height, int width, float* out_dev, int out_height, int out_width, int filter,
+                        void* scratch_dev, size_t scratch_bytes, void* stream);
+int mrisr_gaussian_blur_slices(const float* in_dev, int batch, int height, int width, float sigma, float truncate, float* tmp_dev,
+                               float* out_dev, void* stream);
+size_t mrisr_low_field_scratch_bytes(int batch, int height, int width, float scale_factor);
+int mrisr_simulate_low_field(const float* hr_dev, int batch, int height, int width, float scale_factor, float* lr_dev, void* scratch_dev,
+                             size_t scratch_bytes, void* stream);
 
 /* ---- per-launch HIP-event profiler (bench.py roofline leg; off by default) ------------------------- */
 int mrisr_prof_enable(int on);

@@ -148,6 +148,7 @@ struct mrisr_sampler {
     mrisr_model* unet = nullptr;
     mrisr_model* cnet = nullptr;
     int kind = 0, n_steps = 0, first = 0, last = 0;
+    float clip = 0.f;
     DevBuf d_ts, d_coef, d_step, d_curt, d_eps;
     std::vector<std::unique_ptr<DevBuf>> res_bufs;   // ControlNet -> UNet residuals (NHWC, compute dtype)
     std::vector<std::unique_ptr<DevBuf>> intra_bufs;  // adapter features converted once
@@ -178,7 +179,8 @@ int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_ki
     s->first = 0;
     s->last = n_steps;
     std::vector<long long> ts(timesteps, timesteps + n_steps);
-    std::vector<float> coef((size_t)n_steps * 4, 0.f);
+    MRISR_REQUIRE(step_kind >= MRISR_STEP_DDIM && step_kind <= MRISR_STEP_DDPM, "unknown step kind");
+    std::vector<float> coef((size_t)n_steps * 8, 0.f);
     for (int i = 0; i < n_steps; ++i) {
         const long long t = ts[i];
         MRISR_REQUIRE(t >= 0 && t < n_train, "timestep out of range");
@@ -189,6 +191,16 @@ int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_ki
             const double a_p = tp >= 0 ? alphas_cumprod[tp] : alphas_cumprod[0];
             coef[2 * i] = (float)std::sqrt(a_p / a_t);
             coef[2 * i + 1] = (float)(std::sqrt(1.0 - a_p) - std::sqrt(a_p * (1.0 - a_t) / a_t));
+        } else if (step_kind == MRISR_STEP_DDPM) {
+            // diffusers DDPMScheduler.step, variance_type "fixed_small" (un-vendored; BASELINE config 1)
+            const long long tp = t - n_train / n_steps;
+            const double a_p = tp >= 0 ? alphas_cumprod[tp] : 1.0;
+            const double al = a_t / a_p, be = 1.0 - al;
+            coef[8 * i] = (float)(1.0 / std::sqrt(a_t));
+            coef[8 * i + 1] = (float)(std::sqrt(1.0 - a_t) / std::sqrt(a_t));
+            coef[8 * i + 2] = (float)(std::sqrt(a_p) * be / (1.0 - a_t));
+            coef[8 * i + 3] = (float)(std::sqrt(al) * (1.0 - a_p) / (1.0 - a_t));
+            coef[8 * i + 4] = t > 0 ? (float)std::sqrt(std::max((1.0 - a_p) / (1.0 - a_t) * be, 1e-20)) : 0.f;
         } else {
             // reference res_srdiff.py:83-96: prev_t = timesteps[i+1] or 0; last step uses alpha[0] and no noise
             const long long tp = i + 1 < n_steps ? ts[i + 1] : 0;
@@ -217,13 +229,21 @@ int mrisr_sampler_set_range(mrisr_sampler* s, int first_step, int last_step) {
     return 0;
 }
 
+int mrisr_sampler_set_clip(mrisr_sampler* s, float clip_sample_range) {
+    MRISR_REQUIRE(s, "null sampler");
+    MRISR_REQUIRE(s->kind == MRISR_STEP_DDPM, "x0 clipping belongs to the DDPM step");
+    if (s->clip != clip_sample_range && s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }  // baked into the graph
+    s->clip = clip_sample_range;
+    return 0;
+}
+
 int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tensor* lr_latents,
                       const mrisr_tensor* step_noise, const mrisr_tensor* ehs, const mrisr_tensor* cond,
                       const mrisr_tensor* intrablock, int n_intrablock, int use_graph, void* stream) {
     API_BEGIN
     MRISR_REQUIRE(s && latents && ehs, "null argument");
     MRISR_REQUIRE(latents->ndim == 4 && latents->dtype == MRISR_F32 && latents->layout == MRISR_NCHW, "latents: f32 NCHW");
-    MRISR_REQUIRE(s->kind == MRISR_STEP_DDIM || lr_latents, "Res-SRDiff needs the LR anchor latents");
+    MRISR_REQUIRE(s->kind != MRISR_STEP_RESSHIFT || lr_latents, "Res-SRDiff needs the LR anchor latents");
     MRISR_REQUIRE(!s->cnet || cond, "ControlNet needs the condition image");
     hipStream_t user = (hipStream_t)stream;
     hipStream_t st = user;
@@ -303,6 +323,9 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
                            intra.data(), n_intrablock, &eps_t, st));
         if (s->kind == MRISR_STEP_DDIM)
             TRY(launch_ddim_step((float*)latents->data, (const float*)s->d_eps.p, (const float*)s->d_coef.p, step, n, st));
+        else if (s->kind == MRISR_STEP_DDPM)
+            TRY(launch_ddpm_step((float*)latents->data, (const float*)s->d_eps.p, step_noise ? (const float*)step_noise->data : nullptr,
+                                 (const float*)s->d_coef.p, step, s->clip, n, st));
         else
             TRY(launch_resshift_step((float*)latents->data, (const float*)s->d_eps.p, (const float*)lr_latents->data,
                                      step_noise ? (const float*)step_noise->data : nullptr, (const float*)s->d_coef.p, step, n, st));

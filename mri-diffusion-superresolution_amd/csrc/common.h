@@ -302,6 +302,8 @@ template <typename T> int launch_fill_zero(void* p, long long n, hipStream_t st)
 int launch_ddim_step(float* x, const float* eps, const float* coef_table, const int* step_idx, long long n,
                      hipStream_t st);
 //   res-srdiff reverse step (reference res_srdiff.py:84-96): coef row = {sqrt_at, sqrt_1mat, sqrt_ap, sigma}
+int launch_ddpm_step(float* x, const float* eps, const float* noise, const float* coef_table, const int* step_idx, float clip,
+                     long long n, hipStream_t st);
 int launch_resshift_step(float* x, const float* eps, const float* lr, const float* noise, const float* coef_table,
                          const int* step_idx, long long n, hipStream_t st);
 int launch_advance_step(int* step_idx, hipStream_t st);

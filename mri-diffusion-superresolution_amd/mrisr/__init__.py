@@ -11,3 +11,5 @@ from .train import LoRATrainer, cosine_lr  # noqa: F401
 from .vae import AutoencoderKL, VAEConfig, vae_param_shapes  # noqa: F401
 from .metrics import MRIEvaluator  # noqa: F401
 from .train import AdapterTrainer, joint_step  # noqa: F401
+from .datasets import (FastMRILazyDataset, SliceDataset, gaussian_blur, get_data_dicts_artificial,  # noqa: F401
+                       pad_or_center_crop, resize_slices, simulate_low_field)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmrisr.so")
 
 MRISR_F32, MRISR_BF16, MRISR_F16, MRISR_I64 = 0, 1, 2, 3
 MRISR_NCHW, MRISR_NHWC = 0, 1
-STEP_DDIM, STEP_RESSHIFT = 0, 1
+STEP_DDIM, STEP_RESSHIFT, STEP_DDPM = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
 
 _DT = {torch.float32: MRISR_F32, torch.bfloat16: MRISR_BF16, torch.float16: MRISR_F16, torch.int64: MRISR_I64}
@@ -57,12 +57,14 @@ EXPORTS = [
     "mrisr_model_workspace_bytes", "mrisr_unet_forward", "mrisr_model_set_context", "mrisr_model_num_skips",
     "mrisr_model_skip_shape", "mrisr_controlnet_forward", "mrisr_controlnet_set_cond", "mrisr_adapter_create",
     "mrisr_adapter_destroy", "mrisr_adapter_set_param", "mrisr_adapter_finalize", "mrisr_adapter_forward",
-    "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range",
+    "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range", "mrisr_sampler_set_clip",
     "mrisr_adapter_train_prepare", "mrisr_adapter_train_num_trainable", "mrisr_adapter_train_num_tensors",
     "mrisr_adapter_train_tensor_info", "mrisr_adapter_train_bind", "mrisr_adapter_train_refresh", "mrisr_adapter_backward",
     "mrisr_vae_create", "mrisr_vae_destroy", "mrisr_vae_set_param", "mrisr_vae_num_params", "mrisr_vae_finalize",
     "mrisr_vae_encode", "mrisr_vae_decode",
     "mrisr_image_metrics",
+    "mrisr_resize_scratch_bytes", "mrisr_resize_slices", "mrisr_gaussian_blur_slices", "mrisr_low_field_scratch_bytes",
+    "mrisr_simulate_low_field",
     "mrisr_train_prepare", "mrisr_train_num_trainable", "mrisr_train_num_tensors", "mrisr_train_tensor_info",
     "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_train_set_intrablock_grads", "mrisr_optim_sumsq", "mrisr_optim_adamw", "mrisr_optim_ema",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
@@ -85,6 +87,17 @@ def lib() -> C.CDLL:
         L.mrisr_model_destroy.restype = None
         L.mrisr_adapter_destroy.restype = None
         L.mrisr_sampler_destroy.restype = None
+        L.mrisr_sampler_set_clip.argtypes = [C.c_void_p, C.c_float]
+        L.mrisr_resize_scratch_bytes.restype = C.c_size_t
+        L.mrisr_resize_scratch_bytes.argtypes = [C.c_int] * 6
+        L.mrisr_resize_slices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]
+        L.mrisr_gaussian_blur_slices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
+        L.mrisr_low_field_scratch_bytes.restype = C.c_size_t
+        L.mrisr_low_field_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float]
+        L.mrisr_simulate_low_field.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_void_p]
         L.mrisr_vae_destroy.restype = None
         L.mrisr_vae_destroy.argtypes = [C.c_void_p]
         L.mrisr_vae_num_params.restype = C.c_int64

@@ -59,16 +59,23 @@ class Sampler:
     """Owns a C-ABI sampler (device tables + the captured step graph) for one (unet, controlnet, schedule)."""
 
     def __init__(self, unet: UNet2DConditionModel, scheduler, controlnet: Optional[ControlNetModel] = None,
-                 kind: str = "ddim"):
+                 kind: str = "ddim", clip_sample_range: float = 0.0):
+        """``kind``: "ddim" (eta 0), "resshift" (res_srdiff.py:84-96) or "ddpm" (ancestral, diffusers DDPMScheduler.step with
+        "fixed_small" variance; ``clip_sample_range`` > 0 clips the predicted x0 as diffusers' ``clip_sample`` does)."""
+        kinds = {"ddim": L.STEP_DDIM, "resshift": L.STEP_RESSHIFT, "ddpm": L.STEP_DDPM}
+        if kind not in kinds:
+            raise ValueError(f"unknown sampler kind {kind!r}")
         self.unet, self.controlnet, self.kind = unet, controlnet, kind
         ts = scheduler.timesteps.detach().cpu().to(torch.int64).numpy().copy()
         ac = scheduler.alphas_cumprod.detach().cpu().to(torch.float32).numpy().copy()
         self.n_steps = len(ts)
         self._h = C.c_void_p()
         L.check(L.lib().mrisr_sampler_create(unet._h, controlnet._h if controlnet is not None else None,
-                                             L.STEP_DDIM if kind == "ddim" else L.STEP_RESSHIFT,
+                                             kinds[kind],
                                              ts.ctypes.data_as(C.c_void_p), int(len(ts)),
                                              ac.ctypes.data_as(C.c_void_p), int(len(ac)), C.byref(self._h)))
+        if clip_sample_range > 0:
+            L.check(L.lib().mrisr_sampler_set_clip(self._h, float(clip_sample_range)))
 
     def __del__(self):
         try:

@@ -76,3 +76,21 @@ class OracleScheduler:
         a_p = ac[t_prev] if t_prev >= 0 else ac[0]
         x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
         return a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps
+
+    def ddpm_step(self, eps: torch.Tensor, t: int, x: torch.Tensor, noise=None, clip_sample_range: float = 0.0) -> torch.Tensor:
+        """Ancestral step of diffusers' DDPMScheduler.step (un-vendored; variance_type "fixed_small", epsilon prediction;
+        BASELINE config 1 "10-step DDPM").  ``noise`` is the z ~ N(0, I) the scheduler would draw (None: mean only)."""
+        ac = self.alphas_cumprod.to(x.dtype)
+        t_prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = ac[t]
+        a_p = ac[t_prev] if t_prev >= 0 else torch.ones((), dtype=x.dtype)
+        alpha_t = a_t / a_p
+        beta_t = 1 - alpha_t
+        x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        if clip_sample_range > 0:
+            x0 = x0.clamp(-clip_sample_range, clip_sample_range)
+        mean = (a_p.sqrt() * beta_t / (1 - a_t)) * x0 + (alpha_t.sqrt() * (1 - a_p) / (1 - a_t)) * x
+        if t > 0 and noise is not None:
+            var = ((1 - a_p) / (1 - a_t) * beta_t).clamp(min=1e-20)
+            mean = mean + var.sqrt() * noise
+        return mean

@@ -281,3 +281,46 @@ def test_config1_mnist_plumbing_ddim10(golden_dir):
     torch.cuda.synchronize()
     assert rel(lat, traj[-1]) < 1e-3 and maxrel(lat, traj[-1]) < 1e-3
     assert lat[:, :, 2:30, 2:30].shape == (8, 1, 28, 28)
+
+
+@pytest.mark.parametrize("clip", [0.0, 1.0])
+def test_config1_mnist_plumbing_ddpm10(clip):
+    """BASELINE config 1 as worded ("10-step DDPM, bs=8"): the ancestral step with per-step noise, with and without diffusers'
+    default x0 clipping, on the 1-channel 2-level UNet.  HIP sampler (f32, graph replay) vs the CPU oracle loop, 1e-3 rel."""
+    import mrisr
+    from oracle import sampler as osa
+    from oracle import schedulers as osch
+    from oracle import unet as ou
+    cfg = ou.MNIST
+    p = ou.init_unet_params(cfg, seed=57, perturb_norm=True)
+    g = torch.Generator().manual_seed(58)
+    x = torch.randn((8, 1, 32, 32), generator=g)
+    ctx = torch.randn((8, 77, cfg.cross_attention_dim), generator=g)
+    z = torch.randn((10, 8, 1, 32, 32), generator=g)
+    so = osch.OracleScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear")
+    so.set_timesteps(10)
+    traj = osa.ddpm_sample(ou.OracleUNet(p, cfg), x, ctx, so, z, clip)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32")
+    net.load_state_dict(p)
+    sp = mrisr.DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear")
+    sp.set_timesteps(10)
+    for graph in (True, False):
+        lat = x.cuda().clone().contiguous()
+        mrisr.Sampler(net, sp, kind="ddpm", clip_sample_range=clip).run(lat, ctx.cuda(), step_noise=z.cuda(), use_graph=graph)
+        torch.cuda.synchronize()
+        assert rel(lat, traj[-1]) < 1e-3 and maxrel(lat, traj[-1]) < 1e-3, (graph, rel(lat, traj[-1]))
+    assert not torch.allclose(traj[-1], osa.ddpm_sample(ou.OracleUNet(p, cfg), x, ctx, so, None, clip)[-1])  # the noise matters
+
+
+def test_sampler_kind_errors():
+    import mrisr
+    from oracle import unet as ou
+    net = mrisr.UNet2DConditionModel(ou.MNIST, compute_dtype="f32")
+    net.load_state_dict(ou.init_unet_params(ou.MNIST, seed=1))
+    sp = mrisr.DDIMScheduler()
+    sp.set_timesteps(4)
+    with pytest.raises(ValueError):
+        mrisr.Sampler(net, sp, kind="euler")
+    with pytest.raises(RuntimeError):  # x0 clipping is a DDPM option
+        L = mrisr._lib
+        L.check(L.lib().mrisr_sampler_set_clip(mrisr.Sampler(net, sp, kind="ddim")._h, 1.0))

@@ -129,6 +129,7 @@ struct GemmArgs {
     const void* lora_a = nullptr;
     int lora_R = 0;
     float* lora_zout = nullptr;
+    int dbg = 0;  // cross-check switches (mrisr_debug_gemm_flags): 8 scalar LoRA up-projection, 16 unstaged head-major stores
 };
 
 template <typename T> int launch_gemm(const GemmArgs& g, hipStream_t st);

@@ -62,10 +62,34 @@ __device__ __forceinline__ void load4<bf16>(const bf16* p, float* v) {
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 
+// V^T [b][h][d][token]: a lane of the MFMA result holds 4 d-values of ONE token, so a direct store is 4 x 2 bytes at a token
+// stride.  Exchange with the 3 neighbouring token lanes (fr ^ 1, fr ^ 2) so that every lane ends up with 4 consecutive
+// tokens (w0 = tokens 4k, 4k+1; w1 = 4k+2, 4k+3, bf16 pairs) of ONE d row, whose index (0..3) is returned: a single 8-byte
+// store.  All four lanes of an exchange must be active together (tile rows and M are multiples of 4).
+__device__ __forceinline__ int exchange_tokens4(const float* v, unsigned& w0, unsigned& w1) {
+    const int fr = threadIdx.x & 15;
+    const bool odd = fr & 1;
+    const float s0 = __shfl_xor(odd ? v[0] : v[2], 1);
+    const float s1 = __shfl_xor(odd ? v[1] : v[3], 1);
+    // even lane: rows d0,d1 for tokens (t, t+1); odd lane: rows d2,d3 for tokens (t-1, t)
+    const float a0 = odd ? s0 : v[0], a1 = odd ? v[2] : s0;   // row A: (token lo, token hi)
+    const float c0 = odd ? s1 : v[1], c1 = odd ? v[3] : s1;   // row C
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 pa = {(bf16)a0, (bf16)a1}, pc = {(bf16)c0, (bf16)c1};
+    const unsigned ua = __builtin_bit_cast(unsigned, pa), uc = __builtin_bit_cast(unsigned, pc);
+    const bool hi2 = fr & 2;
+    // lanes (fr&2)==0 keep row A and hand row C to fr^2; lanes (fr&2)!=0 keep row C and hand row A over
+    const unsigned recv = __shfl_xor(hi2 ? ua : uc, 2);
+    w0 = hi2 ? recv : ua;
+    w1 = hi2 ? uc : recv;
+    return (odd ? 2 : 0) + (hi2 ? 1 : 0);  // even/odd picks (d0|d1) vs (d2|d3); hi2 picks the second of the pair
+}
+
 // v: accumulated values (already summed over K) for columns n0..n0+3 (GEGLU: u values; gate in vg).
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg, const float* zl = nullptr,
-                                          T* lds_dst = nullptr, bool resid_later = false, bool mfma_lanes = true) {
+                                          T* lds_dst = nullptr, bool resid_later = false, bool mfma_lanes = true, T* lds_t = nullptr,
+                                          int ml = 0, int nl = 0, int tpitch = 0) {
     const float alpha = g.alpha;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.act == ACT_GEGLU) {
@@ -136,6 +160,16 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
     } else if (g.out_mode == OUT_F32) {
         store4<float>(reinterpret_cast<float*>(g.out) + zoff + (size_t)m * g.ldo + n0, v);
     } else {  // OUT_HEADS
+        if (lds_dst) {  // staged, [token][channel] section: the tile leaves through LDS as whole (token, head) rows
+            store4<T>(lds_dst, v);
+            return;
+        }
+        if (sizeof(T) == 2 && lds_t) {  // staged, transposed section: LDS tile is [channel][token]
+            unsigned w0, w1;
+            const int drow = exchange_tokens4(v, w0, w1);
+            *reinterpret_cast<uint2*>(lds_t + (nl + drow) * tpitch + (ml & ~3)) = make_uint2(w0, w1);
+            return;
+        }
         const int s = n0 / g.secC;
         const int c = n0 - s * g.secC;
         const int h = c / g.hd;
@@ -150,28 +184,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
         } else if (sizeof(T) == 2 && mfma_lanes && (g.ntok & 3) == 0 && (g.M & 3) == 0) {
             // (only from the MFMA kernels, where lanes fr ^ 1, fr ^ 2 hold the neighbouring tokens - NOT from the split-K
             // reduce kernel, whose threads walk the output linearly)
-            // V^T [b][h][d][token]: the lane holds 4 d-values of ONE token, so a direct store is 4 x 2 bytes at a
-            // token stride.  Exchange with the 3 neighbouring token lanes (fr ^ 1, fr ^ 2) so that every lane ends up
-            // with 4 consecutive tokens of ONE d row: a single 8-byte store (all lanes of the exchange are valid
-            // together: tile rows and M are multiples of 4).
-            const int fr = threadIdx.x & 15;
-            const bool odd = fr & 1;
-            const float s0 = __shfl_xor(odd ? v[0] : v[2], 1);
-            const float s1 = __shfl_xor(odd ? v[1] : v[3], 1);
-            // even lane: rows d0,d1 for tokens (t, t+1); odd lane: rows d2,d3 for tokens (t-1, t)
-            const float a0 = odd ? s0 : v[0], a1 = odd ? v[2] : s0;   // row A: (token lo, token hi)
-            const float c0 = odd ? s1 : v[1], c1 = odd ? v[3] : s1;   // row C
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-            const bf16x2 pa = {(bf16)a0, (bf16)a1}, pc = {(bf16)c0, (bf16)c1};
-            const unsigned ua = __builtin_bit_cast(unsigned, pa), uc = __builtin_bit_cast(unsigned, pc);
-            const bool hi2 = fr & 2;
-            // lanes (fr&2)==0 keep row A and hand row C to fr^2; lanes (fr&2)!=0 keep row C and hand row A over
-            const unsigned recv = __shfl_xor(hi2 ? ua : uc, 2);
-            const unsigned w0 = hi2 ? recv : ua, w1 = hi2 ? uc : recv;  // tokens (4k,4k+1) then (4k+2,4k+3)
-            // which d row this lane now owns: even/odd picks (d0|d1) vs (d2|d3); hi2 picks the second of the pair
-            const int drow = (odd ? 2 : 0) + (hi2 ? 1 : 0);
-            const int tok4 = tok & ~3;
-            T* o = base + (bh * g.dpad + dd + drow) * g.npad + tok4;
+            unsigned w0, w1;
+            const int drow = exchange_tokens4(v, w0, w1);
+            T* o = base + (bh * g.dpad + dd + drow) * g.npad + (tok & ~3);
             *reinterpret_cast<uint2*>(o) = make_uint2(w0, w1);
         } else {
             T* o = base + (bh * g.dpad + dd) * g.npad + tok;
@@ -456,6 +471,40 @@ __device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* oti
     }
 }
 
+// head-major outputs (OUT_HEADS) of a tile that lies inside ONE section: [token][channel] sections are staged like row outputs
+// and leave as 16-byte pieces of the (token, head) rows - consecutive tokens are adjacent in [b][h][token][d], so a tile
+// writes long runs; transposed sections (V^T [b][h][d][token]) are staged as [channel][token] and leave as 16 bytes = 8
+// tokens of one d row (BM tokens = one contiguous run per row).  Before: 8-byte stores from the accumulator layout.
+template <int BM, int BN>
+__device__ __forceinline__ void copy_out_heads(const GemmArgs& g, const bf16* otile, int m0, int n0, bool tr) {
+    __syncthreads();
+    const int s = n0 / g.secC;
+    bf16* base = reinterpret_cast<bf16*>(s == 0 ? g.sec_ptr[0] : (s == 1 ? g.sec_ptr[1] : g.sec_ptr[2]));
+    if (!tr) {
+        constexpr int CPR = BN / 8, P = BN + 8;
+        for (int idx = threadIdx.x; idx < BM * CPR; idx += 256) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (m >= g.M || n >= g.N) continue;
+            const int c = n - s * g.secC, h = c / g.hd, dd = c - h * g.hd;
+            const int b = m / g.ntok, tok = m - b * g.ntok;
+            *reinterpret_cast<bf16x8*>(base + (((size_t)b * g.nheads + h) * g.npad + tok) * g.dpad + dd) =
+                *reinterpret_cast<const bf16x8*>(otile + row * P + ch * 8);
+        }
+    } else {
+        constexpr int TPC = BM / 8, P = BM + 8;
+        for (int idx = threadIdx.x; idx < BN * TPC; idx += 256) {
+            const int col = idx / TPC, tc = idx - col * TPC;
+            const int n = n0 + col, m = m0 + tc * 8;
+            if (m >= g.M || n >= g.N) continue;
+            const int c = n - s * g.secC, h = c / g.hd, dd = c - h * g.hd;
+            const int b = m / g.ntok, tok = m - b * g.ntok;
+            *reinterpret_cast<bf16x8*>(base + (((size_t)b * g.nheads + h) * g.dpad + dd) * g.npad + tok) =
+                *reinterpret_cast<const bf16x8*>(otile + col * P + tc * 8);
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -678,6 +727,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
         }
         __syncthreads();
     }
+    // rank-4 adapters: the up-projection out += z (s B)^T is one more K step on the matrix cores - z (bf16) as the row
+    // operand, the 16 x BN slab of s*B (this lane's row, its section's 4 columns, everything else zero) as the weight
+    // operand - instead of 16 FMAs and four 16-byte loads per 4 outputs in the epilogue (which cost 0.35 ms per step).
+    bool lora_mma = false;
+    if (LORA) {
+        lora_mma = g.lora_r == 4 && g.alpha == 1.0f && !(g.dbg & 8);
+        if (lora_mma) {
+            bf16x8 zf[MF];
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                zf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (fg < 2) {
+                    const float* zp = zlds + (wm0 + j * 16 + fr) * 16 + fg * 8;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(zp), b = *reinterpret_cast<const f32x4*>(zp + 4);
+                    zf[j] = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int n = n0 + wn0 + i * 16 + fr;
+                bf16x8 bfr = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (n < g.N) {
+                    const int sec = n / g.lora_secN;  // this column's adapter slot: z columns [4 sec, 4 sec + 4)
+                    if ((sec >> 1) == fg) {
+                        const f32x4 l = *reinterpret_cast<const f32x4*>(g.lora_b + (size_t)n * 4);
+                        if (sec & 1) { bfr[4] = (bf16)l[0]; bfr[5] = (bf16)l[1]; bfr[6] = (bf16)l[2]; bfr[7] = (bf16)l[3]; }
+                        else { bfr[0] = (bf16)l[0]; bfr[1] = (bf16)l[1]; bfr[2] = (bf16)l[2]; bfr[3] = (bf16)l[3]; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, zf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
     if (g.splitk > 1) {
         float* part = g.partial + ((size_t)z * g.splitk + split) * (size_t)g.M * g.N;
 #pragma unroll
@@ -718,6 +801,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
     const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && g.heads == 1 && g.stage_out;
     // the residual is then added in the copy-out pass (whole-row reads; the staged value is already rounded to bf16)
     const bool resid_later = staged && g.resid != nullptr && (g.ldr & 7) == 0 && g.stage_out < 3;
+    // head-major outputs: staged when the tile lies inside one section (Q, K or V) and everything is 8-aligned
+    bool hstaged = false, htr = false;
+    if (g.out_mode == OUT_HEADS && g.stage_out && !(g.dbg & 16)) {
+        const int sec = n0 / g.secC;
+        hstaged = (min(n0 + BN, g.N) - 1) / g.secC == sec && ((g.N | g.M | g.hd | g.secC | g.dpad | g.npad | g.ntok) & 7) == 0 && g.heads == 1 &&
+                  g.batch == 1;
+        htr = (sec == 0 ? g.sec_tr[0] : (sec == 1 ? g.sec_tr[1] : g.sec_tr[2])) != 0;
+    }
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -726,11 +817,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, z, m, n, v, nullptr, LORA ? zlds + (m - m0) * 16 : nullptr,
-                             staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later);
+                epilogue4<T>(g, z, m, n, v, nullptr, LORA && !lora_mma ? zlds + (m - m0) * 16 : nullptr,
+                             staged || (hstaged && !htr) ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later, true,
+                             hstaged && htr ? otile : nullptr, m - m0, n - n0, BM + 8);
             }
         }
     if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, z, resid_later);
+    else if (hstaged) copy_out_heads<BM, BN>(g, otile, m0, n0, htr);
 }
 
 // =================================================================================================
@@ -1492,6 +1585,10 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
 // Chooses tile + split-K for g (sets g.tile / g.splitk).  Deterministic per signature within a process.
 static int g_force_split = 0;  // test hook: split-K factor for every GEMM that can be split (exercises the reduce kernel's epilogue)
 extern "C" void mrisr_debug_force_split(int s) { g_force_split = s; }
+// test hook / MRISR_GEMM_FLAGS: 8 = LoRA up-projection in the scalar epilogue instead of the matrix cores, 16 = head-major outputs
+// stored straight from the accumulator layout instead of through LDS (the older code paths, kept as cross-checks)
+static int g_gemm_flags = [] { const char* e = getenv("MRISR_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
+extern "C" void mrisr_debug_gemm_flags(int f) { g_gemm_flags = f; }
 static int g_prefer_tile = 0;  // test hook: use this specialised kernel (halo 41-45 / weight-stationary 50-52) wherever it is eligible
 extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
 
@@ -1540,6 +1637,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
     static const int stage_env = [] { const char* e = getenv("MRISR_STAGE_OUT"); return e ? atoi(e) : 2; }();  // 0 off, 1 tiled kernels, 2 + halo kernels (default), 3: as 2 but residual added before staging
     const_cast<GemmArgs&>(g).stage_out = stage_env;
+    const_cast<GemmArgs&>(g).dbg = g_gemm_flags;
     int tile = g.tile ? g.tile : g_force_tile, s = g.splitk;
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
     if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;

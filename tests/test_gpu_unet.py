@@ -86,6 +86,46 @@ def test_unet_with_every_gemm_split(tiny, dt, tol):
         lib.mrisr_debug_force_split(C.c_int(0))
 
 
+def test_staged_head_scatter_and_mfma_lora_match_the_direct_paths():
+    """bf16 GEMM epilogues have two forms each: head-major Q / K / V^T outputs staged through LDS vs stored straight from the
+    accumulator layout (flag 16), and the rank-4 LoRA up-projection on the matrix cores vs in the scalar epilogue (flag 8).
+    Staging must not change a single bit; the matrix-core form rounds z and s*B to bf16 first, so both forms are measured against
+    the f32 engine and must be equally close.  Head sizes 40 / 80 (SD-1.5 levels 0 / 1) so that every alignment condition of the staged path holds."""
+    import ctypes as C
+    import mrisr
+    from mrisr import _lib as L
+    from mrisr import params as P
+    cfg = mrisr.UNetConfig(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                           layers_per_block=1)
+    dev = torch.device("cuda")
+    sd = P.random_state_dict(P.unet_param_shapes(cfg), 77, dev)
+    sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), 78, dev))
+    g = torch.Generator(device=dev).manual_seed(79)
+    x = torch.randn((4, 4, 32, 32), generator=g, device=dev)
+    ctx = torch.randn((4, 77, cfg.cross_attention_dim), generator=g, device=dev)
+    t = torch.tensor([1, 250, 600, 999], device=dev)
+    lib = L.lib()
+    outs = {}
+    try:
+        for flags in (0, 16, 8):
+            lib.mrisr_debug_gemm_flags(C.c_int(flags))
+            net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
+            net.load_state_dict(sd)
+            outs[flags] = net(x, t, encoder_hidden_states=ctx).sample.float().clone()
+            torch.cuda.synchronize()
+    finally:
+        lib.mrisr_debug_gemm_flags(C.c_int(0))
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().mean()) > 1e-3
+    assert torch.equal(outs[0], outs[16])
+    ref = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4)
+    ref.load_state_dict(sd)
+    f32 = ref(x, t, encoder_hidden_states=ctx).sample.float()
+    e_mma, e_scalar = rel(outs[0], f32), rel(outs[8], f32)
+    print(f"bf16 vs f32: matrix-core LoRA {e_mma:.4e}, scalar-epilogue LoRA {e_scalar:.4e}, between them {rel(outs[0], outs[8]):.4e}")
+    assert e_mma < 5e-2 and e_scalar < 5e-2
+    assert e_mma < 1.25 * e_scalar + 1e-3, (e_mma, e_scalar)   # rounding z / s*B to bf16 does not cost accuracy against f32
+
+
 @pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("bf16", 5e-2)])
 def test_unet_materialised_attention_path(tiny, dt, tol):
     import mrisr

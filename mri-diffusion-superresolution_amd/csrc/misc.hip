@@ -60,6 +60,51 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
     }
 }
 
+// One row (a scalar timestep: every sample shares the embedding), bf16 weights, K <= 2048: the stack of all per-block time
+// projections is a 50 MB weight stream.  act(x) is computed once per workgroup into LDS (not once per wave and k), a wave owns
+// TWO output columns and issues every weight load of both before the first use, so the pass runs at bandwidth, not latency.
+__global__ __launch_bounds__(256) void gemv_row1_kernel(const float* __restrict__ x, const bf16* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int N, int K, int silu_in) {
+    __shared__ __attribute__((aligned(16))) float xs[2048];
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float v = x[k];
+        xs[k] = silu_in ? silu_f(v) : v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (n0 >= N) return;
+    const int n1 = min(n0 + 1, N - 1);
+    bf16x8 wa[4], wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane * 8 + j * 512;
+        if (k < K) {
+            wa[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)n0 * K + k);
+            wb[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)n1 * K + k);
+        }
+    }
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane * 8 + j * 512;
+        if (k < K) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xs + k), hi = *reinterpret_cast<const f32x4*>(xs + k + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a += lo[e] * (float)wa[j][e] + hi[e] * (float)wa[j][4 + e];
+                b += lo[e] * (float)wb[j][e] + hi[e] * (float)wb[j][4 + e];
+            }
+        }
+    }
+    a = wsum(a);
+    b = wsum(b);
+    if (lane == 0) {
+        y[n0] = a + (bias ? bias[n0] : 0.f);
+        if (n0 + 1 < N) y[n0 + 1] = b + (bias ? bias[n0 + 1] : 0.f);
+    }
+}
+
 // Several rows (per-sample timesteps: rows = batch): the same product on the matrix cores.  A wave owns 16 output
 // columns; per 32-deep k step it streams one W fragment (16 n x 32 k, 16 B per lane) and builds NB x fragments
 // (16 rows x 32 k) from the tiny L2-resident f32 input, applying SiLU and rounding to bf16 on the way.
@@ -117,6 +162,11 @@ int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, 
         else if (rows <= 32) hipLaunchKernelGGL((gemv_rows_mfma_kernel<2>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
         else if (rows <= 48) hipLaunchKernelGGL((gemv_rows_mfma_kernel<3>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
         else hipLaunchKernelGGL((gemv_rows_mfma_kernel<4>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
+        MRISR_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (sizeof(T) == 2 && rows == 1 && K % 8 == 0 && K <= 2048) {
+        hipLaunchKernelGGL(gemv_row1_kernel, dim3((N + 7) / 8), dim3(256), 0, st, x, reinterpret_cast<const bf16*>(w), bias, y, N, K, silu_in);
         MRISR_CHECK_HIP(hipGetLastError());
         return 0;
     }

@@ -1,6 +1,6 @@
 // GroupNorm(+SiLU) over NHWC activations (with the skip-concat of two sources folded into the read),
 // LayerNorm over token rows, and the row softmax of the f32 parity attention.  All HBM-bound: 16-byte
-// vector accesses, f32 statistics, deterministic two-stage reductions (no float atomics).
+// vector accesses, f32 statistics, deterministic fixed-order reductions (no float atomics).
 #include "common.h"
 #include "prof.h"
 
@@ -171,6 +171,176 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs a, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GroupNorm in ONE pass (bf16): a workgroup owns one image and a slab of whole groups (slab = a multiple of lcm(8, C/groups)
+// channels) and keeps its part of the image in registers - NV 16-byte vectors per thread, all loaded before the first use -
+// so the activation is read once instead of twice and the statistics never leave the CU.  Per-channel sums are folded
+// through LDS in a fixed order (deterministic), groups are formed from channel sums (a 16-byte vector may straddle two
+// groups: C/groups = 10, 20, 60 ...).  The (sum, sum of squares) pairs also go to the workspace in the two-kernel layout
+// (split 0; the other splits zero) for the backward pass.  All slabs of an image run on one XCD (4 MB L2 absorbs the
+// partial cache lines of the 80...240-byte slab rows); falls back to the two-kernel path when a slab does not fit.
+// ------------------------------------------------------------------------------------------------
+template <int NVM>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, int slab, int slots, int RL, int nslab, int xcd_map) {
+    typedef bf16 T;
+    constexpr int VE = 8;
+    __shared__ float part[256 * 16];   // [tid][s1[8] | s2[8]]
+    __shared__ float seg[2 * 1280];    // stage A of the channel fold: [segment][2 * slab]
+    __shared__ double gsum[2 * 80];    // [which][group of the slab]
+    __shared__ float mean_s[80], rstd_s[80];
+    const int C = a.c0 + a.c1;
+    const int Cg = C / a.groups;
+    int b, sl;
+    if (xcd_map) {  // linear id L: XCD = L % 8 = image % 8  ->  every slab of an image lands on the same XCD
+        const int L = blockIdx.x;
+        b = (L & 7) + 8 * (L / (8 * nslab));
+        sl = (L >> 3) % nslab;
+    } else {
+        b = blockIdx.x / nslab;
+        sl = blockIdx.x - b * nslab;
+    }
+    const int ch0 = sl * slab;
+    const int tid = threadIdx.x;
+    const int slot = tid % slots, rl = tid / slots;
+    const bool active = rl < RL;
+    const int ch = ch0 + slot * VE;
+    const T* src;
+    int ld;
+    if (ch < a.c0) { src = reinterpret_cast<const T*>(a.x0) + (size_t)b * a.HW * a.c0 + ch; ld = a.c0; }
+    else { src = reinterpret_cast<const T*>(a.x1) + (size_t)b * a.HW * a.c1 + (ch - a.c0); ld = a.c1; }
+    bf16x8 xv[NVM];
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s1[e] = s2[e] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NVM; ++i) {
+            const int r = rl + i * RL;
+            if (r < a.HW) xv[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)r * ld);
+        }
+#pragma unroll
+        for (int i = 0; i < NVM; ++i) {
+            if (rl + i * RL < a.HW) {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float f = (float)xv[i][e];
+                    s1[e] += f;
+                    s2[e] += f * f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[tid * 16 + e] = s1[e];
+        part[tid * 16 + 8 + e] = s2[e];
+    }
+    __syncthreads();
+    // channel fold, stage A: output o = which * slab + c, rows split into nseg segments so that all threads work
+    const int nout = 2 * slab;
+    int nseg = 256 / nout;
+    if (nseg < 1) nseg = 1;
+    if (nseg > RL) nseg = RL;
+    const int seg_len = (RL + nseg - 1) / nseg;
+    for (int t = tid; t < nout * nseg; t += 256) {
+        const int o = t % nout, sg = t / nout;
+        const int which = o / slab, c = o - which * slab;
+        const int off = (c >> 3) * 16 + which * 8 + (c & 7);
+        float acc = 0.f;
+        const int r1 = min(RL, (sg + 1) * seg_len);
+        for (int r = sg * seg_len; r < r1; ++r) acc += part[(r * slots) * 16 + off];
+        seg[sg * nout + o] = acc;
+    }
+    __syncthreads();
+    // stage B: a wave per (group, which) pair - lanes take the group's channels x segments, then a shuffle tree
+    const int ng = slab / Cg;
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int p = wave; p < 2 * ng; p += 4) {
+            const int gl = p % ng, which = p / ng;
+            double acc = 0.0;
+            for (int t = lane; t < Cg * nseg; t += 64) {
+                const int sg = t / Cg, c = t - sg * Cg;
+                acc += (double)seg[sg * nout + which * slab + gl * Cg + c];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) gsum[which * 80 + gl] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < ng) {
+        const double a1 = gsum[tid], a2 = gsum[80 + tid];
+        const double n = (double)a.HW * Cg;
+        const double mean = a1 / n;
+        double var = a2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+        const int gq = ch0 / Cg + tid;
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+            float* p = a.partial + (((size_t)b * a.nsplit + sp) * a.groups + gq) * 2;
+            p[0] = sp == 0 ? (float)a1 : 0.f;
+            p[1] = sp == 0 ? (float)a2 : 0.f;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[VE], sh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const int gl = (slot * VE + e) / Cg;
+        const float sv = rstd_s[gl] * a.gamma[ch + e];
+        sc[e] = sv;
+        sh[e] = a.beta[ch + e] - mean_s[gl] * sv;
+    }
+    T* y = reinterpret_cast<T*>(a.y) + (size_t)b * a.HW * C + ch;
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) {
+        const int r = rl + i * RL;
+        if (r < a.HW) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float f = (float)xv[i][e] * sc[e] + sh[e];
+                if (a.silu) f = silu_f(f);
+                o[e] = (bf16)f;
+            }
+            *reinterpret_cast<bf16x8*>(y + (size_t)r * C) = o;
+        }
+    }
+}
+
+static int g_gn_fused = [] { const char* e = getenv("MRISR_GN_FUSED"); return e ? atoi(e) : 1; }();
+extern "C" void mrisr_debug_gn_fused(int on) { g_gn_fused = on; }
+
+// slab / thread geometry of the one-pass kernel for this shape; false: use the two-kernel path
+static bool gn_fused_plan(const GroupNormArgs& a, int* slab_out, int* slots_out, int* rl_out, int* nv_out) {
+    const int C = a.c0 + a.c1, Cg = C / a.groups;
+    int base = Cg;
+    while (base % 8) base += Cg;  // lcm(8, Cg)
+    if (C % base) return false;
+    int best = 0, best_active = 0;
+    for (int f = 1; f * base <= 640 && f * base <= C; ++f) {
+        const int slab = f * base;
+        if (C % slab || a.c0 % 8 || a.c1 % 8) continue;
+        const int slots = slab / 8;
+        if (slots > 256 || slab / Cg > 80) continue;
+        const int RL = min(256 / slots, a.HW);
+        const int nv = (a.HW + RL - 1) / RL;
+        if (nv > 24) continue;
+        const int active = slots * RL;
+        if (active > best_active) { best = slab; best_active = active; }
+        if (active >= 200) break;  // the smallest slab that fills the workgroup: most workgroups
+    }
+    if (!best) return false;
+    *slab_out = best;
+    *slots_out = best / 8;
+    *rl_out = min(256 / *slots_out, a.HW);
+    *nv_out = (a.HW + *rl_out - 1) / *rl_out;
+    return true;
+}
+
 int groupnorm_nsplit(int B, int HW) {
     int ns = 512 / (B > 0 ? B : 1);
     if (ns < 1) ns = 1;
@@ -203,6 +373,28 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
         snprintf(buf, sizeof(buf), " B=%d HW=%d C=%d", a.B, a.HW, C);
         n1 += buf;
         n2 += buf;
+    }
+    if constexpr (sizeof(T) == 2) {
+        int slab = 0, fslots = 0, fRL = 0, nv = 0;
+        if (g_gn_fused && gn_fused_plan(a, &slab, &fslots, &fRL, &nv)) {
+            const int nslab = C / slab;
+            const int xmap = (a.B % 8) == 0 ? 1 : 0;
+            std::string nf = "groupnorm_fused";
+            if (prof_enabled() && prof_shapes()) {
+                char buf[96];
+                snprintf(buf, sizeof(buf), " B=%d HW=%d C=%d", a.B, a.HW, C);
+                nf += buf;
+            }
+            ProfScope ps(prof_intern(nf), 0.0, 2.0 * act_bytes, st);
+            const dim3 fg(a.B * nslab);
+            if (nv <= 2) hipLaunchKernelGGL((gn_fused_kernel<2>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else if (nv <= 4) hipLaunchKernelGGL((gn_fused_kernel<4>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else if (nv <= 8) hipLaunchKernelGGL((gn_fused_kernel<8>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else if (nv <= 16) hipLaunchKernelGGL((gn_fused_kernel<16>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else hipLaunchKernelGGL((gn_fused_kernel<24>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            MRISR_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
     }
     {
     ProfScope ps(prof_intern(n1), 0.0, act_bytes, st);

@@ -95,6 +95,39 @@ def test_groupnorm(dt, B, C, C2, H, silu):
     assert rel(y, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("B,C,C2,H,W,silu", [
+    (8, 320, 0, 32, 32, True), (8, 320, 320, 32, 32, True), (3, 640, 0, 16, 16, True), (8, 1280, 640, 16, 16, False),
+    (8, 640, 320, 16, 16, True), (8, 1280, 0, 8, 8, True), (16, 1280, 1280, 8, 8, True), (8, 1280, 640, 8, 8, True),
+    (5, 1280, 0, 4, 4, True), (8, 1280, 1280, 4, 4, False), (8, 640, 320, 32, 32, True), (8, 64, 0, 5, 7, True),
+    (2, 128, 128, 64, 64, True), (8, 512, 0, 24, 40, False)])
+def test_groupnorm_one_pass_kernel(B, C, C2, H, W, silu):
+    """The one-pass bf16 GroupNorm (image slab in registers) on every UNet / VAE geometry: group widths 2...80 (vectors
+    straddling groups at 10 / 20 / 60 channels per group), skip-concat inside a slab, non-square and odd images, batches that
+    are / are not a multiple of the XCD count, and the (960 channels at 32x32) shape that falls back to the two-kernel path.
+    Checked against torch (bf16 tolerance) and against the two-kernel path (same f32 statistics -> at most 1 bf16 ulp apart)."""
+    import ctypes as C_
+    from mrisr import _lib as L
+    from mrisr import ops
+    x = _rnd((B, C, H, W), "bf16", 114) * 1.7 + 0.3
+    x2 = _rnd((B, C2, H, W), "bf16", 115) * 0.6 - 1.0 if C2 else None
+    g, b = 1 + 0.2 * _rnd((C + C2,), "f32", 116), 0.2 * _rnd((C + C2,), "f32", 117)
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], 1)
+    ref = F.group_norm(xin, 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    lib = L.lib()
+    outs = []
+    try:
+        for on in (1, 0):
+            lib.mrisr_debug_gn_fused(C_.c_int(on))
+            outs.append(ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), 32, 1e-5, silu, x2=x2.cuda() if x2 is not None else None).float().cpu())
+    finally:
+        lib.mrisr_debug_gn_fused(C_.c_int(1))
+    assert rel(outs[0], ref) < TOL["bf16"] and rel(outs[1], ref) < TOL["bf16"]
+    d = (outs[0] - outs[1]).abs()
+    assert float((d / outs[1].abs().clamp_min(0.05)).max()) < 2 ** -6, float((d / outs[1].abs().clamp_min(0.05)).max())
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,C", [(100, 320), (64, 640), (33, 1280), (7, 64)])
 def test_layernorm(dt, M, C):

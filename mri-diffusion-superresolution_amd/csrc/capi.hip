@@ -819,6 +819,16 @@ static int op_conv3x3_t(const mrisr_tensor* x, const mrisr_tensor* x2, const flo
     DevBuf wp, part;
     TRY(wp.reserve((size_t)cout * Cin * 9 * sizeof(T), false));
     TRY(launch_pack_conv3x3<T>(w, wp.p, cout, Cin, 3, st));
+    if (!x2 && !ups && Cin % (128 / (int)sizeof(T)) != 0) {
+        // fan-in below one K tile (conv_in: 4 channels): the direct kernels (matrix-core conv_in form for bf16, 4 channels)
+        DirectConvArgs a;
+        a.x = x->data; a.w = wp.p; a.bias = bias; a.y = y->data; a.B = B; a.Hin = H; a.Win = W; a.Cin = Cin;
+        a.Hout = (H - 1) / stride + 1; a.Wout = (W - 1) / stride + 1; a.Cout = cout; a.ks = 3; a.stride = stride; a.pad = 1; a.act = act;
+        MRISR_REQUIRE(y->shape[1] == cout && y->shape[2] == a.Hout && y->shape[3] == a.Wout, "conv output shape");
+        TRY(launch_direct_conv<T>(a, st));
+        MRISR_CHECK_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
     GemmArgs g;
     g.a0 = x->data; g.c0 = C0; g.lda0 = C0;
     if (x2) { g.a1 = x2->data; g.c1 = C1; g.lda1 = C1; }

@@ -278,6 +278,7 @@ struct DirectConvArgs {
     const void* add = nullptr; // + add[m][n] (T), same shape as y
 };
 template <typename T> int launch_direct_conv(const DirectConvArgs& a, hipStream_t st);
+int direct_conv_prepare();
 // layout / dtype conversion at the boundary.  src dtype is a DType id.
 template <typename T>
 int launch_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int B, int C, int H, int W, hipStream_t st);

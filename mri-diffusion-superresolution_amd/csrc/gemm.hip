@@ -1621,6 +1621,7 @@ int gemm_prepare() {
     if (init_zero_page()) return 1;
     if (prepare_all<float>()) return 1;
     if (prepare_all<bf16>()) return 1;
+    if (direct_conv_prepare()) return 1;
     return prepare_bls();
 }
 

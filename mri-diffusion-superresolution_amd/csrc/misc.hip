@@ -423,9 +423,113 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const DirectConvArgs a)
     }
 }
 
+// conv_in on the matrix cores (bf16, 3x3, 4 input channels, stride 1, pad 1): K = 36 padded to 64 = two MFMA steps.  The filter
+// bank sits in LDS as [Cout][40] (taps 0-7 | tap 8 + zeros), a wave takes 16 consecutive pixels, gathers their 3x3x4
+// neighbourhoods straight into the row fragments (one 8-byte load per tap), runs Cout/16 x 2 MFMAs and leaves through a
+// per-wave LDS tile so that the 16 x Cout outputs - one contiguous run in NHWC - are written as 16-byte pieces.
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const DirectConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    bf16* wl = reinterpret_cast<bf16*>(sm_raw);                                  // [Cout][40]
+    const int OP = a.Cout + 8;
+    bf16* ot = wl + (size_t)a.Cout * 40 + (size_t)(threadIdx.x >> 6) * 16 * OP;  // this wave's [16][Cout + 8]
+    float* bl = reinterpret_cast<float*>(wl + (size_t)a.Cout * 40 + (size_t)4 * 16 * OP);  // [Cout] bias
+    const bf16* x = reinterpret_cast<const bf16*>(a.x);
+    const bf16* w = reinterpret_cast<const bf16*>(a.w);
+    bf16* y = reinterpret_cast<bf16*>(a.y);
+    for (int i = threadIdx.x; i < a.Cout * 10; i += 256) {  // 72-byte filter rows -> 80-byte LDS rows, 8 bytes at a time
+        const int n = i / 10, j = i - n * 10;
+        const uint2 v = j < 9 ? *reinterpret_cast<const uint2*>(w + (size_t)n * 36 + j * 4) : make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(wl + (size_t)n * 40 + j * 4) = v;
+    }
+    for (int i = threadIdx.x; i < a.Cout; i += 256) bl[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+    const int M = a.B * a.Hout * a.Wout;  // < 2^31 (checked by the launcher)
+    const int ngroups = (M + 15) / 16;
+    const int NFR = a.Cout / 16, CPR = a.Cout / 8;
+    for (int pg = blockIdx.x * 4 + (threadIdx.x >> 6); pg < ngroups; pg += gridDim.x * 4) {
+        const int m = pg * 16 + fr;
+        bf16x8 af0 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, af1 = af0;
+        if (m < M) {
+            const int ox = m % a.Wout, oy = (m / a.Wout) % a.Hout, b = m / (a.Wout * a.Hout);
+            auto tap4 = [&](int t) -> uint2 {  // the 4 channels of the pixel under tap t (zeros outside the image)
+                const int ky = t / 3, kx = t - ky * 3;
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                if (iy < 0 || iy >= a.Hin || ix < 0 || ix >= a.Win) return make_uint2(0u, 0u);
+                return *reinterpret_cast<const uint2*>(x + (((size_t)b * a.Hin + iy) * a.Win + ix) * 4);
+            };
+            const uint2 p0 = tap4(fg * 2), p1 = tap4(fg * 2 + 1);
+            af0 = __builtin_bit_cast(bf16x8, make_uint4(p0.x, p0.y, p1.x, p1.y));
+            if (fg == 0) {
+                const uint2 p8 = tap4(8);
+                af1 = __builtin_bit_cast(bf16x8, make_uint4(p8.x, p8.y, 0u, 0u));
+            }
+        }
+        for (int i = 0; i < NFR; ++i) {
+            const bf16* wr = wl + (size_t)(i * 16 + fr) * 40;
+            const bf16x8 wf0 = *reinterpret_cast<const bf16x8*>(wr + fg * 8);
+            bf16x8 wf1 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (fg == 0) wf1 = *reinterpret_cast<const bf16x8*>(wr + 32);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, af0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, af1, acc, 0, 0, 0);
+            const int n = i * 16 + fg * 4;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + n);
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[r] + b4[r];
+                if (a.act == ACT_SILU) v = silu_f(v);
+                else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+                o[r] = (bf16)v;
+            }
+            *reinterpret_cast<bf16x4*>(ot + fr * OP + n) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes (no other wave touches this tile)
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < 16 * CPR; c += 64) {
+            const int row = c / CPR, col = (c - row * CPR) * 8;
+            const int mo = pg * 16 + row;
+            if (mo >= M) continue;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(ot + row * OP + col);
+            if (a.add) {
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.add) + (size_t)mo * a.Cout + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)ad[e]);
+            }
+            *reinterpret_cast<bf16x8*>(y + (size_t)mo * a.Cout + col) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile reads done before the next group overwrites it
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// launch attributes (called from gemm_prepare, i.e. before any graph capture)
+int direct_conv_prepare() {
+    static bool done = false;
+    if (!done) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)conv_in_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        done = true;
+    }
+    return 0;
+}
+
 template <typename T>
 int launch_direct_conv(const DirectConvArgs& a, hipStream_t st) {
     const size_t wbytes = (size_t)a.ks * a.ks * a.Cin * a.Cout * sizeof(T);
+    if (sizeof(T) == 2 && a.ks == 3 && a.Cin == 4 && a.stride == 1 && a.pad == 1 && a.Cout % 16 == 0 && a.Hout == a.Hin && a.Wout == a.Win) {
+        const size_t smem = ((size_t)a.Cout * 40 + (size_t)4 * 16 * (a.Cout + 8)) * 2 + (size_t)a.Cout * 4;
+        if (smem <= 80 * 1024 && (long long)a.B * a.Hout * a.Wout * a.Cout < (1ll << 31)) {  // Cout <= 384: two workgroups per CU
+            if (direct_conv_prepare()) return 1;
+            const long long M = (long long)a.B * a.Hout * a.Wout;
+            long long blocks = ((M + 15) / 16 + 3) / 4;
+            if (blocks > 256) blocks = 256;  // every workgroup first stages the filter bank
+            ProfScope ps("conv_in_mfma", 2.0 * M * a.Cout * 36, 2.0 * (M * 4.0 + (double)M * a.Cout), st);
+            hipLaunchKernelGGL(conv_in_mfma_kernel, dim3((unsigned)blocks), dim3(256), smem, st, a);
+            MRISR_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (a.Cout % 8 == 0 && wbytes <= 48 * 1024) {
         const long long items = (long long)a.B * a.Hout * a.Wout * (a.Cout / 8);
         long long blocks = (items + 255) / 256;

@@ -188,6 +188,22 @@ def test_attention_backward_matches_autograd(B, N, Nk, C, H):
     assert rel(dv, vf.grad) < 2e-2, ("dv", rel(dv, vf.grad))
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride", [(2, 4, 320, 32, 32, 1), (3, 4, 64, 7, 5, 1), (1, 4, 320, 64, 64, 1), (5, 4, 32, 3, 3, 1),
+                                                   (2, 3, 128, 16, 16, 1), (2, 4, 320, 16, 16, 2), (1, 8, 24, 9, 9, 1)])
+def test_conv3x3_small_fan_in(dt, B, Cin, Cout, H, W, stride):
+    """Fan-in below one K tile: conv_in (4 channels; bf16 runs the matrix-core form - image borders, a pixel count that is not a
+    multiple of 16, one wave tile spanning several image rows) and the generic direct kernels (3 / 8 channels, stride 2, f32)."""
+    from mrisr import ops
+    x = _rnd((B, Cin, H, W), dt, 61)
+    w, b = _rnd((Cout, Cin, 3, 3), "f32", 62, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 63)
+    wq = w.to(torch.bfloat16).float() if dt == "bf16" else w
+    ref = F.conv2d(x.float(), wq, b, stride=stride, padding=1)
+    y = ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), stride=stride)
+    assert y.shape == ref.shape
+    assert rel(y, ref) < (4e-3 if dt == "bf16" else 1e-5), rel(y, ref)
+
+
 @pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 25, 26, 27, 28, 29, 30, 31])
 @pytest.mark.parametrize("M,N,K,splitk", [(512, 320, 256, 1), (1000, 640, 384, 1), (256, 1280, 2048, 4), (300, 68, 192, 1),
                                           (4096, 960, 384, 1), (130, 320, 64, 1)])

@@ -489,6 +489,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Short rows (bf16, C = 320 / 640): LPR = 16 / 32 lanes per row, three 16-byte vectors per lane, so a wave normalises 4 / 2
+// rows at once with 83 % of its lanes busy (one wave per row leaves 37 % idle at C = 320) and three loads in flight per lane.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_short_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int M, int C, float eps) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int nvec = C / 8;
+    const bool live = row < M;
+    float v[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int vi = sub + i * LPR;
+        if (live && vi < nvec) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (size_t)row * C + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = (float)t[e];
+                s += v[i][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (live && sub + i * LPR < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int vi = sub + i * LPR;
+        if (live && vi < nvec) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + vi * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + vi * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + vi * 8), b1 = *reinterpret_cast<const f32x4*>(beta + vi * 8 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (bf16)((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+                o[4 + e] = (bf16)((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+            }
+            *reinterpret_cast<bf16x8*>(y + (size_t)row * C + vi * 8) = o;
+        }
+    }
+}
+
 template <typename T>
 int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C, float eps,
                      hipStream_t st) {
@@ -500,6 +559,17 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
     const T* xi = reinterpret_cast<const T*>(x);
     T* yo = reinterpret_cast<T*>(y);
     ProfScope ps("layernorm", 0.0, 2.0 * M * (double)C * sizeof(T), st);
+    if constexpr (sizeof(T) == 2) {
+        static const int short_rows = [] { const char* e = getenv("MRISR_LN_SHORT"); return e ? atoi(e) : 1; }();
+        if (short_rows && nvec <= 96) {
+            const bf16* xb = reinterpret_cast<const bf16*>(x);
+            bf16* yb = reinterpret_cast<bf16*>(y);
+            if (nvec <= 48) hipLaunchKernelGGL((layernorm_short_kernel<16>), dim3((M + 15) / 16), dim3(256), 0, st, xb, yb, gamma, beta, M, C, eps);
+            else hipLaunchKernelGGL((layernorm_short_kernel<32>), dim3((M + 7) / 8), dim3(256), 0, st, xb, yb, gamma, beta, M, C, eps);
+            MRISR_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (need <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
     else if (need <= 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);
     else if (need <= 3) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, dim3(256), 0, st, xi, yo, gamma, beta, M, C, eps);

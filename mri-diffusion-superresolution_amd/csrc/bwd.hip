@@ -183,6 +183,166 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GroupNormBwdArg
     }
 }
 
+// GroupNorm backward in ONE pass (bf16), the mirror of gn_fused_kernel (norm.hip): a workgroup owns one image and a slab of
+// whole groups, keeps x and dy of its part of the image in registers, folds sum(dxhat) and sum(dxhat * xhat) per group through
+// LDS in a fixed order and writes dx from registers - x and dy are read once instead of twice, one launch instead of two.
+template <int NVM>
+__global__ __launch_bounds__(256, 1) void gn_bwd_fused_kernel(const GroupNormBwdArgs a, int slab, int slots, int RL, int nslab, int xcd_map) {
+    typedef bf16 T;
+    constexpr int VE = 8;
+    __shared__ float part[256 * 16];
+    __shared__ float seg[2 * 1280];
+    __shared__ double gsum[2 * 80];
+    __shared__ float mean_s[80], rstd_s[80], m1_s[80], m2_s[80];
+    const int C = a.c0 + a.c1;
+    const int Cg = C / a.groups;
+    int b, sl;
+    if (xcd_map) {
+        const int L = blockIdx.x;
+        b = (L & 7) + 8 * (L / (8 * nslab));
+        sl = (L >> 3) % nslab;
+    } else {
+        b = blockIdx.x / nslab;
+        sl = blockIdx.x - b * nslab;
+    }
+    const int ch0 = sl * slab;
+    const int tid = threadIdx.x;
+    const int ng = slab / Cg;
+    if (tid < ng) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < a.nsplit; ++q) {
+            const size_t o = (((size_t)b * a.nsplit + q) * a.groups + ch0 / Cg + tid) * 2;
+            s1 += (double)a.fwd_partial[o];
+            s2 += (double)a.fwd_partial[o + 1];
+        }
+        const double n = (double)a.HW * Cg;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    const int slot = tid % slots, rl = tid / slots;
+    const bool active = rl < RL;
+    const int ch = ch0 + slot * VE;
+    const bool first = ch < a.c0;
+    const T* src = first ? reinterpret_cast<const T*>(a.x0) + (size_t)b * a.HW * a.c0 + ch
+                         : reinterpret_cast<const T*>(a.x1) + (size_t)b * a.HW * a.c1 + (ch - a.c0);
+    const int ld = first ? a.c0 : a.c1;
+    const T* dyp = reinterpret_cast<const T*>(a.dy) + (size_t)b * a.HW * C + ch;
+    bf16x8 xv[NVM], dv[NVM];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NVM; ++i) {
+            const int r = rl + i * RL;
+            if (r < a.HW) {
+                xv[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)r * ld);
+                dv[i] = *reinterpret_cast<const bf16x8*>(dyp + (size_t)r * C);
+            }
+        }
+    }
+    __syncthreads();
+    float mu[VE], rs[VE], ga[VE], be[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const int gl = (slot * VE + e) / Cg;
+        mu[e] = active ? mean_s[gl] : 0.f;
+        rs[e] = active ? rstd_s[gl] : 0.f;
+        ga[e] = active ? a.gamma[ch + e] : 0.f;
+        be[e] = active ? a.beta[ch + e] : 0.f;
+    }
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s1[e] = s2[e] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NVM; ++i) {
+            if (rl + i * RL < a.HW) {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float xh = ((float)xv[i][e] - mu[e]) * rs[e];
+                    float d = (float)dv[i][e];
+                    if (a.silu) d *= silu_grad(xh * ga[e] + be[e]);
+                    const float dxh = d * ga[e];
+                    s1[e] += dxh;
+                    s2[e] += dxh * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        part[tid * 16 + e] = s1[e];
+        part[tid * 16 + 8 + e] = s2[e];
+    }
+    __syncthreads();
+    const int nout = 2 * slab;
+    int nseg = 256 / nout;
+    if (nseg < 1) nseg = 1;
+    if (nseg > RL) nseg = RL;
+    const int seg_len = (RL + nseg - 1) / nseg;
+    for (int t = tid; t < nout * nseg; t += 256) {
+        const int o = t % nout, sg = t / nout;
+        const int which = o / slab, c = o - which * slab;
+        const int off = (c >> 3) * 16 + which * 8 + (c & 7);
+        float acc = 0.f;
+        const int r1 = min(RL, (sg + 1) * seg_len);
+        for (int r = sg * seg_len; r < r1; ++r) acc += part[(r * slots) * 16 + off];
+        seg[sg * nout + o] = acc;
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int p = wave; p < 2 * ng; p += 4) {
+            const int gl = p % ng, which = p / ng;
+            double acc = 0.0;
+            for (int t = lane; t < Cg * nseg; t += 64) {
+                const int sg = t / Cg, c = t - sg * Cg;
+                acc += (double)seg[sg * nout + which * slab + gl * Cg + c];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) gsum[which * 80 + gl] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < ng) {
+        const double n = (double)a.HW * Cg;
+        m1_s[tid] = (float)(gsum[tid] / n);
+        m2_s[tid] = (float)(gsum[80 + tid] / n);
+    }
+    __syncthreads();
+    if (!active) return;
+    float m1[VE], m2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const int gl = (slot * VE + e) / Cg;
+        m1[e] = m1_s[gl];
+        m2[e] = m2_s[gl];
+    }
+    T* dst = first ? reinterpret_cast<T*>(a.dx0) + (size_t)b * a.HW * a.c0 + ch : reinterpret_cast<T*>(a.dx1) + (size_t)b * a.HW * a.c1 + (ch - a.c0);
+    const bool acc = first ? a.acc0 : a.acc1;
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) {
+        const int r = rl + i * RL;
+        if (r < a.HW) {
+            bf16x8 o;
+            if (acc) o = *reinterpret_cast<const bf16x8*>(dst + (size_t)r * ld);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float xh = ((float)xv[i][e] - mu[e]) * rs[e];
+                float d = (float)dv[i][e];
+                if (a.silu) d *= silu_grad(xh * ga[e] + be[e]);
+                const float dxh = d * ga[e];
+                float g = rs[e] * (dxh - m1[e] - xh * m2[e]);
+                if (acc) g += (float)o[e];
+                o[e] = (bf16)g;
+            }
+            *reinterpret_cast<bf16x8*>(dst + (size_t)r * ld) = o;
+        }
+    }
+}
+
 template <typename T>
 int launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st) {
     constexpr int VE = BVec<T>::N;
@@ -197,6 +357,22 @@ int launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st) {
     if (RL < 1) RL = 1;
     const size_t smem = (size_t)2 * RL * C * sizeof(float);
     const double act_bytes = (double)a.B * a.HW * C * sizeof(T);
+    if constexpr (sizeof(T) == 2) {
+        int slab = 0, fslots = 0, fRL = 0, nv = 0;
+        if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv)) {
+            const int nslab = C / slab;
+            const int xmap = (a.B % 8) == 0 ? 1 : 0;
+            ProfScope ps("groupnorm_bwd_fused", 0.0, 3.0 * act_bytes, st);
+            const dim3 fg(a.B * nslab);
+            if (nv <= 2) hipLaunchKernelGGL((gn_bwd_fused_kernel<2>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else if (nv <= 4) hipLaunchKernelGGL((gn_bwd_fused_kernel<4>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else if (nv <= 8) hipLaunchKernelGGL((gn_bwd_fused_kernel<8>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else if (nv <= 16) hipLaunchKernelGGL((gn_bwd_fused_kernel<16>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            else hipLaunchKernelGGL((gn_bwd_fused_kernel<24>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+            MRISR_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     {
         ProfScope ps("groupnorm_bwd_stats", 0.0, 2.0 * act_bytes, st);
         dim3 grid(a.nsplit, a.B);

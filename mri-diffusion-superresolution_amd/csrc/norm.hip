@@ -314,8 +314,10 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
 static int g_gn_fused = [] { const char* e = getenv("MRISR_GN_FUSED"); return e ? atoi(e) : 1; }();
 extern "C" void mrisr_debug_gn_fused(int on) { g_gn_fused = on; }
 
-// slab / thread geometry of the one-pass kernel for this shape; false: use the two-kernel path
-static bool gn_fused_plan(const GroupNormArgs& a, int* slab_out, int* slots_out, int* rl_out, int* nv_out) {
+// slab / thread geometry of the one-pass kernels for this shape; false: use the two-kernel path
+bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab_out, int* slots_out, int* rl_out, int* nv_out) {
+    if (!g_gn_fused) return false;
+    struct { int c0, c1, groups, HW; } a = {c0, c1, groups, HW};
     const int C = a.c0 + a.c1, Cg = C / a.groups;
     int base = Cg;
     while (base % 8) base += Cg;  // lcm(8, Cg)
@@ -376,7 +378,7 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     }
     if constexpr (sizeof(T) == 2) {
         int slab = 0, fslots = 0, fRL = 0, nv = 0;
-        if (g_gn_fused && gn_fused_plan(a, &slab, &fslots, &fRL, &nv)) {
+        if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv)) {
             const int nslab = C / slab;
             const int xmap = (a.B % 8) == 0 ? 1 : 0;
             std::string nf = "groupnorm_fused";

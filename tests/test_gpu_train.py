@@ -74,6 +74,47 @@ def test_lora_gradients_match_autograd(tiny, dt, tol):
     assert rel(out, pred_ref) < (1e-3 if dt == "f32" else 5e-2)
 
 
+def test_one_pass_groupnorm_forward_and_backward_match_the_two_kernel_path():
+    """bf16 fine-tuning gradients with the one-pass GroupNorm kernels (forward and backward; image slab in registers) against
+    the two-kernel path on an SD-1.5-shaped two-level UNet (320 / 640 channels: 10 and 20 channels per group, skip-concat
+    slabs, SiLU backward inside): same statistics, so loss and the flat LoRA gradient agree to bf16 rounding noise; the
+    f32 engine (always two-kernel) anchors both."""
+    import ctypes as C
+    import mrisr
+    from mrisr import _lib as L
+    from mrisr import params as P
+    cfg = mrisr.UNetConfig(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                           layers_per_block=1)
+    dev = torch.device("cuda")
+    sd = P.random_state_dict(P.unet_param_shapes(cfg), 91, dev)
+    sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), 92, dev))
+    g = torch.Generator(device=dev).manual_seed(93)
+    B, h = 8, 16
+    x = torch.randn((B, 4, h, h), generator=g, device=dev)
+    ctx = torch.randn((B, 77, cfg.cross_attention_dim), generator=g, device=dev)
+    tgt = torch.randn((B, 4, h, h), generator=g, device=dev)
+    t = torch.randint(0, 1000, (B,), generator=g, device=dev)
+    lib = L.lib()
+    res = {}
+    try:
+        for name, dt, fused in (("fused", "bf16", 1), ("two", "bf16", 0), ("f32", "f32", 0)):
+            lib.mrisr_debug_gn_fused(C.c_int(fused))
+            net = mrisr.UNet2DConditionModel(cfg, compute_dtype=dt, lora_rank=4, lora_alpha=4, lora_fused=True)
+            net.load_state_dict(sd)
+            tr = mrisr.LoRATrainer(net)
+            tr.zero_grad()
+            loss = tr.forward_backward(x, t, ctx, tgt)
+            torch.cuda.synchronize()
+            res[name] = (float(loss), tr.grad.detach().float().clone())
+    finally:
+        lib.mrisr_debug_gn_fused(C.c_int(1))
+    e_f, e_t = rel(res["fused"][1], res["f32"][1]), rel(res["two"][1], res["f32"][1])
+    print(f"LoRA gradient vs f32 engine: one-pass GroupNorm {e_f:.3e}, two-kernel {e_t:.3e}; between them {rel(res['fused'][1], res['two'][1]):.3e}")
+    assert abs(res["fused"][0] - res["two"][0]) / res["two"][0] < 2e-3
+    assert e_f < 8e-2 and e_t < 8e-2
+    assert e_f < 1.25 * e_t + 2e-3
+
+
 def test_training_with_adapter_features_and_scalar_timestep(tiny):
     """cfg 3 shape: T2I-Adapter features enter as constants; timestep given as a 0-dim tensor."""
     import mrisr

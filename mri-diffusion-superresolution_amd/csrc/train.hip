@@ -262,14 +262,32 @@ struct Trainer : Runner<T> {
     int linear_bwd(const LinW& lw, const void* x, int ldx, const float* z, const void* dY, int ldy, int M, void* dX, bool acc,
                    bool need_dx) {
         float* dz = nullptr;
+        GemmArgs g;
+        bool in_kernel = false, dx_done = false;
+        if (need_dx) {
+            MRISR_REQUIRE(lw.wT, "linear dgrad weights");
+            g.a0 = dY; g.c0 = lw.n; g.lda0 = ldy;
+            g.w = lw.wT; g.M = M; g.N = lw.k; g.K = lw.n;
+            if (acc) { g.resid = dX; g.ldr = lw.k; }
+            g.out = dX; g.ldo = lw.k;
+            TRY(gemm_choose(g, sizeof(T) == 2));
+            // as in the forward: dz = dY (s B) can ride along the dgrad GEMM (the <= 16 rows of s B^T as extra weight rows)
+            in_kernel = lw.R && sizeof(T) == 2 && lw.R <= 16 && g.splitk == 1 && g.tile >= 14 && lora_in_kernel();
+        }
         if (lw.R) {
             MRISR_REQUIRE(z && lw.loraBT && lw.loraAT && m.grad, "adapter backward state");
             dz = static_cast<float*>(alloc((size_t)M * lw.R * sizeof(float)));
             const size_t sb = std::max(lora_wgrad_scratch_bytes(M, lw.n, lw.R, sizeof(T)), lora_wgrad_scratch_bytes(M, lw.k, lw.R, sizeof(T)));
             float* scratch = static_cast<float*>(alloc(sb));
             if (!dz || !scratch) return 7;
+            if (in_kernel) {  // the dgrad first: it produces dz for the A gradient
+                g.lora_a = lw.loraBT; g.lora_R = lw.R; g.lora_zout = dz;
+                g.lora_zld = lw.R; g.lora_b = lw.loraAT; g.lora_r = lw.R; g.lora_secN = INT_MAX;
+                if (!dry) TRY(launch_gemm<T>(g, st));
+                dx_done = true;
+            }
             if (!dry) {
-                TRY(launch_lora_down<T>(dY, ldy, lw.loraBT, dz, M, lw.n, lw.R, st));
+                if (!in_kernel) TRY(launch_lora_down<T>(dY, ldy, lw.loraBT, dz, M, lw.n, lw.R, st));
                 const int nmod = (int)lw.mod_names.size();
                 float *oA[3] = {nullptr, nullptr, nullptr}, *oB[3] = {nullptr, nullptr, nullptr};
                 for (int j = 0; j < nmod; ++j) {
@@ -281,15 +299,14 @@ struct Trainer : Runner<T> {
                 TRY(launch_lora_wgrad<T>(x, ldx, dz, lw.R, M, lw.k, 1, lw.r, nmod, lw.secN, oA, 1.0f, scratch, st));
             }
         }
-        if (!need_dx) return 0;
-        MRISR_REQUIRE(lw.wT, "linear dgrad weights");
-        GemmArgs g;
-        g.a0 = dY; g.c0 = lw.n; g.lda0 = ldy;
-        g.w = lw.wT; g.M = M; g.N = lw.k; g.K = lw.n;
+        if (!need_dx || dx_done) return 0;
         if (dz) { g.lora_z = dz; g.lora_zld = lw.R; g.lora_b = lw.loraAT; g.lora_r = lw.R; g.lora_secN = INT_MAX; }
-        if (acc) { g.resid = dX; g.ldr = lw.k; }
-        g.out = dX; g.ldo = lw.k;
-        return R::run_gemm(g);
+        if (g.splitk > 1) {
+            g.partial = static_cast<float*>(alloc((size_t)g.splitk * g.batch * g.M * g.N * sizeof(float)));
+            if (!g.partial) return 7;
+        }
+        if (dry) return 0;
+        return launch_gemm<T>(g, st);
     }
 
     struct AttnRec {

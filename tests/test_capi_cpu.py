@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
         ge.build()
     lib = _lib.lib()
     hdr = open(os.path.join(ROOT, "include", "mrisr.h")).read()
-    declared = set(re.findall(r"^(?:int|void|int64_t|const char\*)\s+(mrisr_[a-z0-9_]+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|int64_t|size_t|const char\*)\s+(mrisr_[a-z0-9_]+)\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing

@@ -299,6 +299,8 @@ int launch_pack_rows(const float* src, int rows, int cols, void* dst, int ld_dst
 // conv weight [Cout][Cin][3][3] f32 -> [Cout][ky][kx][Cin] T
 template <typename T>
 int launch_pack_conv3x3(const float* src, void* dst, int Cout, int Cin, int ks, hipStream_t st);
+template <typename T>
+int launch_pack_conv3x3_padded(const float* src, void* dst, int Cout, int Cin, int ks, int Cout_pad, int Cin_pad, hipStream_t st);
 int launch_pack_bias_geglu(const float* src, float* dst, int half, hipStream_t st);
 template <typename T> int launch_fill_zero(void* p, long long n, hipStream_t st);
 // sampler steps (f32 state, NCHW like the reference's latents)

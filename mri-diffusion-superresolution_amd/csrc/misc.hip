@@ -692,6 +692,25 @@ __global__ void pack_conv_kernel(const float* src, T* dst, int Cout, int Cin, in
         dst[i] = from_f32<T>(src[((size_t)n * Cin + c) * ks * ks + tap]);
     }
 }
+// the same filter bank with both channel counts padded up (zeros): dst [Cout_pad][ky][kx][Cin_pad]
+template <typename T>
+__global__ void pack_conv_padded_kernel(const float* src, T* dst, int Cout, int Cin, int ks, int Cout_pad, int Cin_pad) {
+    const long long total = (long long)Cout_pad * Cin_pad * ks * ks;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % Cin_pad);
+        const long long t = i / Cin_pad;
+        const int tap = (int)(t % (ks * ks));
+        const int n = (int)(t / (ks * ks));
+        dst[i] = from_f32<T>(n < Cout && c < Cin ? src[((size_t)n * Cin + c) * ks * ks + tap] : 0.f);
+    }
+}
+template <typename T>
+int launch_pack_conv3x3_padded(const float* src, void* dst, int Cout, int Cin, int ks, int Cout_pad, int Cin_pad, hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv_padded_kernel<T>, dim3(nblocks((long long)Cout_pad * Cin_pad * ks * ks)), dim3(256), 0, st, src,
+                       reinterpret_cast<T*>(dst), Cout, Cin, ks, Cout_pad, Cin_pad);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 template <typename T>
 int launch_pack_conv3x3(const float* src, void* dst, int Cout, int Cin, int ks, hipStream_t st) {
     hipLaunchKernelGGL(pack_conv_kernel<T>, dim3(nblocks((long long)Cout * Cin * ks * ks)), dim3(256), 0, st, src,
@@ -820,6 +839,7 @@ int launch_resshift_forward(const float* hr, const float* lr, const float* noise
     template int launch_pixel_unshuffle_nchw<T>(const void*, int, void*, int, int, int, int, int, hipStream_t);    \
     template int launch_pack_rows<T>(const float*, int, int, void*, int, int, int, int, int, float, hipStream_t);  \
     template int launch_pack_conv3x3<T>(const float*, void*, int, int, int, hipStream_t);                          \
+    template int launch_pack_conv3x3_padded<T>(const float*, void*, int, int, int, int, int, hipStream_t);         \
     template int launch_fill_zero<T>(void*, long long, hipStream_t);
 INST(float)
 INST(bf16)

@@ -473,7 +473,10 @@ struct Runner {
         TRY(import_act(cond, &e, false));
         for (size_t k = 0; k < m.ce.size(); ++k) {
             const bool last = k + 1 == m.ce.size();
-            TRY(direct(e, m.ce[k], m.ce_stride[k], last ? ACT_NONE : ACT_SILU, nullptr, &y));
+            const int act = last ? ACT_NONE : ACT_SILU;
+            constexpr int KQ = 128 / (int)sizeof(T);
+            if (e.C % KQ == 0 && m.ce[k].cout % 4 == 0) TRY(conv3(e, nullptr, m.ce[k], m.ce_stride[k], 0, nullptr, 0, 1, nullptr, act, &y));
+            else TRY(direct(e, m.ce[k], m.ce_stride[k], act, nullptr, &y));  // the first layer (3 input channels)
             e = y;
         }
         MRISR_REQUIRE(e.numel() * sizeof(T) <= m.cond_emb_bytes, "condition embedding larger than planned");

@@ -84,3 +84,21 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t1) / reps
 print(f"{which}: B={B} latents {h}x{h}, {nsteps}-step DDIM: {dt * 1e3:.1f} ms per batch = {B / dt:.2f} slices/s, "
       f"{dt * 1e3 / nsteps:.2f} ms per denoising step, finite={bool(torch.isfinite(lat).all())}")
+if "--profile" in sys.argv:  # per-shape kernel classes of one eager denoising step (MRISR_PROF_SHAPES=1 for shapes)
+    from mrisr import _lib as L
+    lib = L.lib()
+    smp.set_range(0, 1)
+    lat.copy_(x_T)
+    smp.run(lat, ctx, controlnet_cond=cond, adapter_features=feats, use_graph=False)
+    torch.cuda.synchronize()
+    lib.mrisr_prof_reset()
+    lib.mrisr_prof_enable(1)
+    smp.run(lat, ctx, controlnet_cond=cond, adapter_features=feats, use_graph=False)
+    torch.cuda.synchronize()
+    lib.mrisr_prof_enable(0)
+    cls = bench.prof_report(lib)
+    tot = sum(v["ms"] for v in cls.values())
+    print(f"eager profile: total {tot:.3f} ms/step")
+    for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+        tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
+        print(f"{k:76s} {v['launches']:4d} {v['ms']:8.4f} {100 * v['ms'] / tot:6.2f} {tf:7.0f}")

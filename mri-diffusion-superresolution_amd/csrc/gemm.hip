@@ -673,6 +673,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
     const int wm0 = (wave / WGN) * WTM, wn0 = (wave % WGN) * WTN;
     const int fr = lane & 15, fg = lane >> 4;
     const bool zwave = LORA && (wave % WGN) == 0;  // the wave column that also accumulates z for its rows
+    // rank-4 adapters: this lane's slab of s*B for the up-projection MFMA after the loop (row n, its section's 4 columns,
+    // everything else zero) - fetched now so that the loop hides the latency
+    const bool lora_mma = LORA && g.lora_r == 4 && g.alpha == 1.0f && !(g.dbg & 8);
+    bf16x8 lbf[NF];
+    if (LORA) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            lbf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            const int n = n0 + wn0 + i * 16 + fr;
+            if (lora_mma && n < g.N) {
+                const int sec = n / g.lora_secN;  // this column's adapter slot: z columns [4 sec, 4 sec + 4)
+                if ((sec >> 1) == fg) {
+                    const f32x4 l = *reinterpret_cast<const f32x4*>(g.lora_b + (size_t)n * 4);
+                    if (sec & 1) { lbf[i][4] = (bf16)l[0]; lbf[i][5] = (bf16)l[1]; lbf[i][6] = (bf16)l[2]; lbf[i][7] = (bf16)l[3]; }
+                    else { lbf[i][0] = (bf16)l[0]; lbf[i][1] = (bf16)l[1]; lbf[i][2] = (bf16)l[2]; lbf[i][3] = (bf16)l[3]; }
+                }
+            }
+        }
+    }
     f32x4 zacc[MF];
 #pragma unroll
     for (int j = 0; j < MF; ++j) zacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -730,36 +749,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
     // rank-4 adapters: the up-projection out += z (s B)^T is one more K step on the matrix cores - z (bf16) as the row
     // operand, the 16 x BN slab of s*B (this lane's row, its section's 4 columns, everything else zero) as the weight
     // operand - instead of 16 FMAs and four 16-byte loads per 4 outputs in the epilogue (which cost 0.35 ms per step).
-    bool lora_mma = false;
-    if (LORA) {
-        lora_mma = g.lora_r == 4 && g.alpha == 1.0f && !(g.dbg & 8);
-        if (lora_mma) {
-            bf16x8 zf[MF];
+    if (LORA && lora_mma) {
+        bf16x8 zf[MF];
 #pragma unroll
-            for (int j = 0; j < MF; ++j) {
-                zf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (fg < 2) {
-                    const float* zp = zlds + (wm0 + j * 16 + fr) * 16 + fg * 8;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(zp), b = *reinterpret_cast<const f32x4*>(zp + 4);
-                    zf[j] = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int n = n0 + wn0 + i * 16 + fr;
-                bf16x8 bfr = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (n < g.N) {
-                    const int sec = n / g.lora_secN;  // this column's adapter slot: z columns [4 sec, 4 sec + 4)
-                    if ((sec >> 1) == fg) {
-                        const f32x4 l = *reinterpret_cast<const f32x4*>(g.lora_b + (size_t)n * 4);
-                        if (sec & 1) { bfr[4] = (bf16)l[0]; bfr[5] = (bf16)l[1]; bfr[6] = (bf16)l[2]; bfr[7] = (bf16)l[3]; }
-                        else { bfr[0] = (bf16)l[0]; bfr[1] = (bf16)l[1]; bfr[2] = (bf16)l[2]; bfr[3] = (bf16)l[3]; }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, zf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MF; ++j) {
+            zf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (fg < 2) {
+                const float* zp = zlds + (wm0 + j * 16 + fr) * 16 + fg * 8;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(zp), b = *reinterpret_cast<const f32x4*>(zp + 4);
+                zf[j] = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
             }
         }
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbf[i], zf[j], acc[i][j], 0, 0, 0);
     }
     if (g.splitk > 1) {
         float* part = g.partial + ((size_t)z * g.splitk + split) * (size_t)g.M * g.N;

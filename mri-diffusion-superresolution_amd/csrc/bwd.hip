@@ -1050,6 +1050,43 @@ __global__ __launch_bounds__(256) void im2col_tap_T_kernel(const T* __restrict__
         if (c < C && m < Mpad) out[(size_t)c * Mpad + m] = tile[tx][i];
     }
 }
+// every tap at once (blockIdx.z = tap): out[(tap * C + c)][m] - the K-major operand of ONE pixel-contraction GEMM per conv
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_all_T_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C, int Ho,
+                                                           int Wo, int stride, int pad, int ks, int M, int Mpad) {
+    __shared__ T tile[32][33];
+    const int tap = blockIdx.z, ky = tap / ks, kx = tap - ky * ks;
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int m = m0 + i, c = c0 + tx;
+        T v = from_f32<T>(0.f);
+        if (m < M && c < C) {
+            const int hw = Ho * Wo;
+            const int b = m / hw, r = m - b * hw;
+            const int oy = r / Wo, ox = r - oy * Wo;
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * H + iy) * W + ix) * C + c];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, m = m0 + tx;
+        if (c < C && m < Mpad) out[((size_t)tap * C + c) * Mpad + m] = tile[tx][i];
+    }
+}
+template <typename T>
+int launch_im2col_all_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ks, int Mpad,
+                        hipStream_t st) {
+    const int M = B * Ho * Wo;
+    MRISR_REQUIRE(Mpad >= M, "im2col: padded pixel count");
+    ProfScope ps("im2col_all_T", 0.0, (1.0 + ks * ks) * M * (double)C * sizeof(T), st);
+    hipLaunchKernelGGL(im2col_all_T_kernel<T>, dim3((Mpad + 31) / 32, (C + 31) / 32, ks * ks), dim3(256), 0, st, reinterpret_cast<const T*>(x),
+                       reinterpret_cast<T*>(out), B, H, W, C, Ho, Wo, stride, pad, ks, M, Mpad);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 template <typename T>
 int launch_im2col_tap_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ky, int kx,
                         int Mpad, hipStream_t st) {
@@ -1097,6 +1134,22 @@ int launch_colsum(const void* dy, float* out, int M, int C, hipStream_t st) {
 // gw[i * taps + tap] += tmp[i]   (tmp: this tap's [Cout][Cin] product)
 __global__ void wgrad_accum_kernel(const float* __restrict__ tmp, float* gw, long long n, int taps, int tap) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) gw[i * taps + tap] += tmp[i];
+}
+// gw[(co * Cin + ci) * taps + tap] += tmp[co][tap * Cin + ci]   (tmp: the all-taps product [Cout][taps * Cin])
+__global__ void wgrad_accum_all_kernel(const float* __restrict__ tmp, float* gw, int Cout, int Cin, int taps) {
+    const long long n = (long long)Cout * Cin * taps;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {  // i walks gw (coalesced writes)
+        const int tap = (int)(i % taps);
+        const long long cc = i / taps;
+        const int ci = (int)(cc % Cin);
+        const long long co = cc / Cin;
+        gw[i] += tmp[(co * taps + tap) * Cin + ci];
+    }
+}
+int launch_wgrad_accum_all(const float* tmp, float* gw, int Cout, int Cin, int taps, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_accum_all_kernel, dim3(bw_blocks((long long)Cout * Cin * taps)), dim3(256), 0, st, tmp, gw, Cout, Cin, taps);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_accum_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, tmp, gw, n, taps, tap);
@@ -1146,6 +1199,7 @@ int launch_ema(float* ema, const float* theta, long long n, float decay, hipStre
     template int launch_sumpool2<T>(const void*, void*, int, int, int, int, int, hipStream_t);                              \
     template int launch_mse_grad<T>(const void*, const float*, void*, float*, int, int, int, int, hipStream_t);                  \
     template int launch_im2col_tap_T<T>(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t); \
+    template int launch_im2col_all_T<T>(const void*, void*, int, int, int, int, int, int, int, int, int, int, hipStream_t);                    \
     template int launch_relu_bwd<T>(const void*, const void*, void*, long long, hipStream_t);                                   \
     template int launch_colsum<T>(const void*, float*, int, int, hipStream_t);                                                   \
     template int launch_pack_conv_dgrad<T>(const float*, void*, int, int, hipStream_t);

@@ -481,26 +481,25 @@ struct AdRunner {
         MRISR_REQUIRE(cw.offW >= 0 && a.grad, "adapter gradient vector not bound");
         const int M = (int)dy.rows(), Mpad = (M + 63) / 64 * 64, taps = cw.ks * cw.ks, pad = cw.ks / 2;
         const size_t mk = a.arena.mark();
+        // ONE pixel-contraction GEMM per conv: dW[co][tap * Cin + ci] = sum_m dY^T[co][m] * im2col^T[tap * Cin + ci][m]
+        // (one transposed im2col launch for all taps, one GEMM, one scatter-add into the PyTorch layout; per-tap GEMMs
+        // meant 27 launches per conv)
         T* dyT = static_cast<T*>(alloc((size_t)cw.cout * Mpad * sizeof(T)));
-        T* xT = static_cast<T*>(alloc((size_t)cw.cin * Mpad * sizeof(T)));
-        float* tmp = static_cast<float*>(alloc((size_t)cw.cout * cw.cin * sizeof(float)));
+        T* xT = static_cast<T*>(alloc((size_t)taps * cw.cin * Mpad * sizeof(T)));
+        float* tmp = static_cast<float*>(alloc((size_t)cw.cout * taps * cw.cin * sizeof(float)));
         if (!dyT || !xT || !tmp) return 7;
         if (!dry) {
             if (Mpad != M) MRISR_CHECK_HIP(hipMemsetAsync(dyT, 0, (size_t)cw.cout * Mpad * sizeof(T), st));
             TRY(launch_transpose<T>(dy.p, dyT, M, cw.cout, cw.cout, Mpad, 0, 0, 1, M, st));
             if (cw.offB >= 0) TRY(launch_colsum<T>(dy.p, a.grad + cw.offB, M, cw.cout, st));
+            TRY(launch_im2col_all_T<T>(x.p, xT, x.B, x.H, x.W, x.C, dy.H, dy.W, stride, pad, cw.ks, Mpad, st));
         }
-        for (int tap = 0; tap < taps; ++tap) {
-            if (!dry) TRY(launch_im2col_tap_T<T>(x.p, xT, x.B, x.H, x.W, x.C, dy.H, dy.W, stride, pad, tap / cw.ks, tap % cw.ks, Mpad, st));
-            GemmArgs g;
-            g.a0 = dyT; g.c0 = Mpad; g.lda0 = Mpad;
-            g.w = xT; g.M = cw.cout; g.N = cw.cin; g.K = Mpad;
-            g.out_mode = OUT_F32; g.out = tmp; g.ldo = cw.cin;
-            const size_t mk2 = a.arena.mark();
-            TRY(gemm(g));
-            a.arena.release(mk2);
-            if (!dry) TRY(launch_wgrad_accum(tmp, a.grad + cw.offW, (long long)cw.cout * cw.cin, taps, tap, st));
-        }
+        GemmArgs g;
+        g.a0 = dyT; g.c0 = Mpad; g.lda0 = Mpad;
+        g.w = xT; g.M = cw.cout; g.N = taps * cw.cin; g.K = Mpad;
+        g.out_mode = OUT_F32; g.out = tmp; g.ldo = taps * cw.cin;
+        TRY(gemm(g));
+        if (!dry) TRY(launch_wgrad_accum_all(tmp, a.grad + cw.offW, cw.cout, cw.cin, taps, st));
         a.arena.release(mk);
         return 0;
     }

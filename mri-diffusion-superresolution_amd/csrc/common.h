@@ -212,6 +212,10 @@ int launch_im2col_tap_T(const void* x, void* out, int B, int H, int W, int C, in
 template <typename T> int launch_relu_bwd(const void* dy, const void* h, void* out, long long n, hipStream_t st);
 template <typename T> int launch_colsum(const void* dy, float* out, int M, int C, hipStream_t st);
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st);
+int launch_wgrad_accum_all(const float* tmp, float* gw, int Cout, int Cin, int taps, hipStream_t st);
+template <typename T>
+int launch_im2col_all_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ks, int Mpad,
+                        hipStream_t st);
 template <typename T> int launch_pack_conv_dgrad(const float* w, void* wd, int Cout, int Cin, hipStream_t st);
 int launch_sumsq(const float* g, long long n, float* out, hipStream_t st);
 int launch_ema(float* ema, const float* theta, long long n, float decay, hipStream_t st);

@@ -160,7 +160,7 @@ int mrisr_sampler_set_clip(mrisr_sampler* s, float clip_sample_range);
  * state-dict keys via tensor_info) and its gradient.  After train_prepare / train_bind, mrisr_adapter_forward keeps what the
  * backward needs; mrisr_adapter_backward takes the gradients w.r.t. the four feature maps (what mrisr_train_step wrote
  * through mrisr_train_set_intrablock_grads) and ADDS dW, db of every conv to the gradient vector (dgrad convs + one
- * pixel-contraction GEMM per filter tap).  refresh re-packs the kernels' weight layouts after the optimiser step. */
+ * pixel-contraction GEMM per conv).  refresh re-packs the kernels' weight layouts after the optimiser step. */
 int mrisr_adapter_train_prepare(mrisr_adapter* a, void* stream);
 int64_t mrisr_adapter_train_num_trainable(const mrisr_adapter* a);
 int mrisr_adapter_train_num_tensors(const mrisr_adapter* a);

@@ -129,6 +129,7 @@ struct GemmArgs {
     const void* lora_a = nullptr;
     int lora_R = 0;
     float* lora_zout = nullptr;
+    int group_m = 1;  // M tiles per group of the tile order (set by the launchers: auto_group_m; MRISR_GROUP_M)
     int dbg = 0;  // cross-check switches (mrisr_debug_gemm_flags): 8 scalar LoRA up-projection, 16 unstaged head-major stores
 };
 

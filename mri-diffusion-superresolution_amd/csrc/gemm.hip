@@ -238,7 +238,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tn = logical % ntn, tm = logical / ntn;
+    // grouped order: within a group of `group_m` M tiles walk M first, so the workgroups that run together on an XCD share
+    // their weight tiles (group_m ways) as well as their activation tiles through that XCD's L2 (N-first order re-streamed
+    // the whole weight matrix once per M tile: 3-6x the algorithmic bytes on the wide-N and deep-K layers)
+    int tn, tm;
+    {
+        const int GM = g.group_m > 1 ? g.group_m : 1;
+        const int per_group = GM * ntn;
+        const int grp = logical / per_group;
+        const int first_m = grp * GM;
+        const int gsz = min(GM, ntm - first_m);
+        const int within = logical - grp * per_group;
+        tm = first_m + within % gsz;
+        tn = within / gsz;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const T* a0 = reinterpret_cast<const T*>(g.a0) + (size_t)z * g.a_bs;
@@ -545,7 +558,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tn = logical % ntn, tm = logical / ntn;
+    // grouped order: within a group of `group_m` M tiles walk M first, so the workgroups that run together on an XCD share
+    // their weight tiles (group_m ways) as well as their activation tiles through that XCD's L2 (N-first order re-streamed
+    // the whole weight matrix once per M tile: 3-6x the algorithmic bytes on the wide-N and deep-K layers)
+    int tn, tm;
+    {
+        const int GM = g.group_m > 1 ? g.group_m : 1;
+        const int per_group = GM * ntn;
+        const int grp = logical / per_group;
+        const int first_m = grp * GM;
+        const int gsz = min(GM, ntm - first_m);
+        const int within = logical - grp * per_group;
+        tm = first_m + within % gsz;
+        tn = within / gsz;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const T* a0p = reinterpret_cast<const T*>(g.a0) + (size_t)z * g.a_bs;
@@ -870,7 +896,20 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tn = logical % ntn, tm = logical / ntn;
+    // grouped order: within a group of `group_m` M tiles walk M first, so the workgroups that run together on an XCD share
+    // their weight tiles (group_m ways) as well as their activation tiles through that XCD's L2 (N-first order re-streamed
+    // the whole weight matrix once per M tile: 3-6x the algorithmic bytes on the wide-N and deep-K layers)
+    int tn, tm;
+    {
+        const int GM = g.group_m > 1 ? g.group_m : 1;
+        const int per_group = GM * ntn;
+        const int grp = logical / per_group;
+        const int first_m = grp * GM;
+        const int gsz = min(GM, ntm - first_m);
+        const int within = logical - grp * per_group;
+        tm = first_m + within % gsz;
+        tn = within / gsz;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int img = m0 / (Hd * Wd);
     const int y0 = (m0 - img * Hd * Wd) / Wd;  // first output row of the tile inside its image
@@ -1154,6 +1193,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------
+// M tiles per group of the tile order (MRISR_GROUP_M overrides; 1 = the old N-first order).  8 measured best over the whole
+// step (same box, graph replay: 53.9 slices/s vs 53.0 for N-first; a per-grid sqrt(T * BN / BM) model: 53.1 vs 53.6): profiles/r01e_group_m.log
+static int auto_group_m(int ntm, int ntn, int BM, int BN) {
+    (void)ntn; (void)BM; (void)BN;
+    static const int env = [] { const char* e = getenv("MRISR_GROUP_M"); return e ? atoi(e) : 8; }();
+    return std::max(1, std::min(env, ntm));
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN>
 static int prepare_cfg() {
     constexpr int smem = 2 * (BM + BN) * 128;
@@ -1179,6 +1226,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_kernel<T, BM, BN, WGM, WGN>;
     if (prepare_cfg<T, BM, BN, WGM, WGN>()) return 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const_cast<GemmArgs&>(g).group_m = auto_group_m(ntm, ntn, BM, BN);
     dim3 grid(ntn * ntm, g.splitk, g.batch);
     static const std::string pname = std::string("gemm_") + (sizeof(T) == 2 ? "bf16_" : "f32_") + std::to_string(BM) + "x" + std::to_string(BN);
     double fl = g.alg_flops, by = g.alg_bytes;
@@ -1216,6 +1264,7 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     constexpr int smem_l = NSTAGE * ((BM + BN) * 128 + 16 * 128);
     if (prepare_bl<BM, BN, WGM, WGN, NSTAGE>()) return 1;
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const_cast<GemmArgs&>(g).group_m = auto_group_m(ntm, ntn, BM, BN);
     dim3 grid(ntn * ntm, g.splitk, g.batch);
     static const std::string base_name = std::string("gemm_bf16_bl") + std::to_string(BM) + "x" + std::to_string(BN) + (NSTAGE > 2 ? "d" + std::to_string(NSTAGE) : std::string());
     std::string pname = base_name;
@@ -1299,6 +1348,7 @@ static int launch_halo(const GemmArgs& g, hipStream_t st) {
         attr = 96 * 1024;
     }
     const int ntn = (g.N + BN - 1) / BN, ntm = g.M / BM;
+    const_cast<GemmArgs&>(g).group_m = auto_group_m(ntm, ntn, BM, BN);
     dim3 grid(ntn * ntm, g.splitk, 1);
     static const std::string base_name = std::string("gemm_bf16_halo") + std::to_string(BM) + "x" + std::to_string(BN);
     std::string pname = base_name;

@@ -39,8 +39,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bh = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * (16 * QF);
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs by their linear id, so the default (query block, head)
+    // grid spreads the query blocks of ONE head over all 8 private L2s and each of them fetches that head's K / V.  With the
+    // remap every query block of a head lands on the same XCD: its K / V tiles are fetched once and hit in L2 afterwards.
+    int bh = blockIdx.y, qblk = blockIdx.x;
+    if (a.xcd_map) {
+        const int L = blockIdx.x + blockIdx.y * gridDim.x;
+        const int slot = L >> 3;
+        bh = (slot / (int)gridDim.x) * 8 + (L & 7);
+        qblk = slot % (int)gridDim.x;
+    }
+    const int q0 = (qblk * 4 + wave) * (16 * QF);
     const bf16* qb = reinterpret_cast<const bf16*>(a.q) + (size_t)bh * ((a.nq + 63) / 64 * 64) * DPAD;
     const bf16* kb = reinterpret_cast<const bf16*>(a.k) + (size_t)bh * a.nkpad * DPAD;
     const bf16* vb = reinterpret_cast<const bf16*>(a.vt) + (size_t)bh * DPAD * a.nkpad;
@@ -209,6 +218,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 template <int DPAD, int DB>
 static int launch_dpad(const AttnArgs& a, hipStream_t st) {
     const int BH = a.B * a.H;
+    static const int xcd_env = [] { const char* e = getenv("MRISR_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    const_cast<AttnArgs&>(a).xcd_map = (xcd_env && BH % 8 == 0) ? 1 : 0;
     ProfScope ps("flash_attention", 4.0 * BH * (double)a.nq * a.nk * a.hd,
                  2.0 * BH * (2.0 * a.nq * a.hd + 2.0 * a.nk * a.hd), st);
     if (a.nq >= 128) {

@@ -235,6 +235,7 @@ struct AttnArgs {
     int B = 0, H = 0, nq = 0, nk = 0, nkpad = 0, hd = 0, dpad = 0;
     float scale = 1.0f;
     float* lse = nullptr;  // optional [B*H][npad]: log2-domain log-sum-exp of scale*s (training keeps it for the backward)
+    int xcd_map = 0;       // set by the launcher: all query blocks of a head on one XCD (needs B*H % 8 == 0)
 };
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);
 // flash attention backward (attn.hip): P is recomputed from Q, K and the forward's log-sum-exp, never materialised.

@@ -272,8 +272,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bh = blockIdx.y;
-    const int own0 = (blockIdx.x * 4 + wave) * (16 * QF);
+    int bh = blockIdx.y, oblk = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {  // all owner blocks of a head on one XCD (as in the forward): the streamed tiles hit its L2
+        const int L = blockIdx.x + blockIdx.y * gridDim.x;
+        const int slot = L >> 3;
+        bh = (slot / (int)gridDim.x) * 8 + (L & 7);
+        oblk = slot % (int)gridDim.x;
+    }
+    const int own0 = (oblk * 4 + wave) * (16 * QF);
     const int own_pad = MODE == 0 ? a.npad : a.nkpad, own_valid = MODE == 0 ? a.nq : a.nk;
     const int str_pad = MODE == 0 ? a.nkpad : a.npad, str_valid = MODE == 0 ? a.nk : a.nq;
     const bf16* x1 = reinterpret_cast<const bf16*>(MODE == 0 ? a.q : a.k) + (size_t)bh * own_pad * DPAD;

@@ -1643,6 +1643,8 @@ extern "C" void mrisr_debug_force_split(int s) { g_force_split = s; }
 // stored straight from the accumulator layout instead of through LDS (the older code paths, kept as cross-checks)
 static int g_gemm_flags = [] { const char* e = getenv("MRISR_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
 extern "C" void mrisr_debug_gemm_flags(int f) { g_gemm_flags = f; }
+// tools/table_search.py: overrides one entry of the tile table in this process (key as in the table file)
+extern "C" void mrisr_debug_set_tuned(const char* key, int tile, int split) { g_tuned[key] = {tile, split}; }
 static int g_prefer_tile = 0;  // test hook: use this specialised kernel (halo 41-45 / weight-stationary 50-52) wherever it is eligible
 extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
 

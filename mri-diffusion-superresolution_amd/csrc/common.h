@@ -158,7 +158,7 @@ struct GroupNormArgs {
 };
 int groupnorm_nsplit(int B, int HW);
 // geometry of the one-pass (image slab in registers) GroupNorm kernels, forward and backward; false: two-kernel path
-bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab, int* slots, int* rl, int* nv);
+bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab, int* slots, int* rl, int* nv, int ve = 8);
 template <typename T> int launch_groupnorm(const GroupNormArgs& a, hipStream_t st);
 template <typename T>
 int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C, float eps,

@@ -180,11 +180,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs a, in
 // (split 0; the other splits zero) for the backward pass.  All slabs of an image run on one XCD (4 MB L2 absorbs the
 // partial cache lines of the 80...240-byte slab rows); falls back to the two-kernel path when a slab does not fit.
 // ------------------------------------------------------------------------------------------------
-template <int NVM>
+template <int NVM, int VE>
 __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, int slab, int slots, int RL, int nslab, int xcd_map) {
     typedef bf16 T;
-    constexpr int VE = 8;
-    __shared__ float part[256 * 16];   // [tid][s1[8] | s2[8]]
+    typedef __attribute__((ext_vector_type(VE))) __bf16 vec_t;  // 16-byte (VE = 8) or 8-byte (VE = 4) channel vectors
+    __shared__ float part[256 * 16];   // [tid][s1[VE] at 0 | s2[VE] at 8]
     __shared__ float seg[2 * 1280];    // stage A of the channel fold: [segment][2 * slab]
     __shared__ double gsum[2 * 80];    // [which][group of the slab]
     __shared__ float mean_s[80], rstd_s[80];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
     int ld;
     if (ch < a.c0) { src = reinterpret_cast<const T*>(a.x0) + (size_t)b * a.HW * a.c0 + ch; ld = a.c0; }
     else { src = reinterpret_cast<const T*>(a.x1) + (size_t)b * a.HW * a.c1 + (ch - a.c0); ld = a.c1; }
-    bf16x8 xv[NVM];
+    vec_t xv[NVM];
     float s1[VE], s2[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) s1[e] = s2[e] = 0.f;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
 #pragma unroll
         for (int i = 0; i < NVM; ++i) {
             const int r = rl + i * RL;
-            if (r < a.HW) xv[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)r * ld);
+            if (r < a.HW) xv[i] = *reinterpret_cast<const vec_t*>(src + (size_t)r * ld);
         }
 #pragma unroll
         for (int i = 0; i < NVM; ++i) {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
     for (int t = tid; t < nout * nseg; t += 256) {
         const int o = t % nout, sg = t / nout;
         const int which = o / slab, c = o - which * slab;
-        const int off = (c >> 3) * 16 + which * 8 + (c & 7);
+        const int off = (c / VE) * 16 + which * 8 + (c % VE);
         float acc = 0.f;
         const int r1 = min(RL, (sg + 1) * seg_len);
         for (int r = sg * seg_len; r < r1; ++r) acc += part[(r * slots) * 16 + off];
@@ -299,14 +299,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
     for (int i = 0; i < NVM; ++i) {
         const int r = rl + i * RL;
         if (r < a.HW) {
-            bf16x8 o;
+            vec_t o;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
                 float f = (float)xv[i][e] * sc[e] + sh[e];
                 if (a.silu) f = silu_f(f);
                 o[e] = (bf16)f;
             }
-            *reinterpret_cast<bf16x8*>(y + (size_t)r * C) = o;
+            *reinterpret_cast<vec_t*>(y + (size_t)r * C) = o;
         }
     }
 }
@@ -315,18 +315,18 @@ static int g_gn_fused = [] { const char* e = getenv("MRISR_GN_FUSED"); return e 
 extern "C" void mrisr_debug_gn_fused(int on) { g_gn_fused = on; }
 
 // slab / thread geometry of the one-pass kernels for this shape; false: use the two-kernel path
-bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab_out, int* slots_out, int* rl_out, int* nv_out) {
+bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab_out, int* slots_out, int* rl_out, int* nv_out, int ve) {
     if (!g_gn_fused) return false;
     struct { int c0, c1, groups, HW; } a = {c0, c1, groups, HW};
     const int C = a.c0 + a.c1, Cg = C / a.groups;
     int base = Cg;
-    while (base % 8) base += Cg;  // lcm(8, Cg)
+    while (base % ve) base += Cg;  // lcm(ve, Cg)
     if (C % base) return false;
     int best = 0, best_active = 0;
     for (int f = 1; f * base <= 640 && f * base <= C; ++f) {
         const int slab = f * base;
-        if (C % slab || a.c0 % 8 || a.c1 % 8) continue;
-        const int slots = slab / 8;
+        if (C % slab || a.c0 % ve || a.c1 % ve) continue;
+        const int slots = slab / ve;
         if (slots > 256 || slab / Cg > 80) continue;
         const int RL = min(256 / slots, a.HW);
         const int nv = (a.HW + RL - 1) / RL;
@@ -337,7 +337,7 @@ bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab_out, int* s
     }
     if (!best) return false;
     *slab_out = best;
-    *slots_out = best / 8;
+    *slots_out = best / ve;
     *rl_out = min(256 / *slots_out, a.HW);
     *nv_out = (a.HW + *rl_out - 1) / *rl_out;
     return true;
@@ -378,7 +378,15 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
     }
     if constexpr (sizeof(T) == 2) {
         int slab = 0, fslots = 0, fRL = 0, nv = 0;
-        if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv)) {
+        if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv, 8)) {
+            // fewer than two workgroups per CU: their load / fold / store phases cannot overlap - try slabs of 8-byte vectors
+            // (half the channels per slab, twice the workgroups)
+            int ve = 8, s4 = 0, sl4 = 0, rl4 = 0, nv4 = 0;
+            static const int ve4_ok = [] { const char* e = getenv("MRISR_GN_VE4"); return e ? atoi(e) : 1; }();
+            if (ve4_ok && a.B * (C / slab) < 512 && gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &s4, &sl4, &rl4, &nv4, 4) &&
+                a.B * (C / s4) > a.B * (C / slab)) {
+                ve = 4; slab = s4; fslots = sl4; fRL = rl4; nv = nv4;
+            }
             const int nslab = C / slab;
             const int xmap = (a.B % 8) == 0 ? 1 : 0;
             std::string nf = "groupnorm_fused";
@@ -389,11 +397,13 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
             }
             ProfScope ps(prof_intern(nf), 0.0, 2.0 * act_bytes, st);
             const dim3 fg(a.B * nslab);
-            if (nv <= 2) hipLaunchKernelGGL((gn_fused_kernel<2>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else if (nv <= 4) hipLaunchKernelGGL((gn_fused_kernel<4>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else if (nv <= 8) hipLaunchKernelGGL((gn_fused_kernel<8>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else if (nv <= 16) hipLaunchKernelGGL((gn_fused_kernel<16>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else hipLaunchKernelGGL((gn_fused_kernel<24>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+#define GN_GO(NV, VEV) hipLaunchKernelGGL((gn_fused_kernel<NV, VEV>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap)
+            if (ve == 8) {
+                if (nv <= 2) GN_GO(2, 8); else if (nv <= 4) GN_GO(4, 8); else if (nv <= 8) GN_GO(8, 8); else if (nv <= 16) GN_GO(16, 8); else GN_GO(24, 8);
+            } else {
+                if (nv <= 2) GN_GO(2, 4); else if (nv <= 4) GN_GO(4, 4); else if (nv <= 8) GN_GO(8, 4); else if (nv <= 16) GN_GO(16, 4); else GN_GO(24, 4);
+            }
+#undef GN_GO
             MRISR_CHECK_HIP(hipGetLastError());
             return 0;
         }

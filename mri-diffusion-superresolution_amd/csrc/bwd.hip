@@ -186,10 +186,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GroupNormBwdArg
 // GroupNorm backward in ONE pass (bf16), the mirror of gn_fused_kernel (norm.hip): a workgroup owns one image and a slab of
 // whole groups, keeps x and dy of its part of the image in registers, folds sum(dxhat) and sum(dxhat * xhat) per group through
 // LDS in a fixed order and writes dx from registers - x and dy are read once instead of twice, one launch instead of two.
-template <int NVM>
+template <int NVM, int VE>
 __global__ __launch_bounds__(256, 1) void gn_bwd_fused_kernel(const GroupNormBwdArgs a, int slab, int slots, int RL, int nslab, int xcd_map) {
     typedef bf16 T;
-    constexpr int VE = 8;
+    typedef __attribute__((ext_vector_type(VE))) __bf16 vec_t;
     __shared__ float part[256 * 16];
     __shared__ float seg[2 * 1280];
     __shared__ double gsum[2 * 80];
@@ -230,14 +230,14 @@ __global__ __launch_bounds__(256, 1) void gn_bwd_fused_kernel(const GroupNormBwd
                          : reinterpret_cast<const T*>(a.x1) + (size_t)b * a.HW * a.c1 + (ch - a.c0);
     const int ld = first ? a.c0 : a.c1;
     const T* dyp = reinterpret_cast<const T*>(a.dy) + (size_t)b * a.HW * C + ch;
-    bf16x8 xv[NVM], dv[NVM];
+    vec_t xv[NVM], dv[NVM];
     if (active) {
 #pragma unroll
         for (int i = 0; i < NVM; ++i) {
             const int r = rl + i * RL;
             if (r < a.HW) {
-                xv[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)r * ld);
-                dv[i] = *reinterpret_cast<const bf16x8*>(dyp + (size_t)r * C);
+                xv[i] = *reinterpret_cast<const vec_t*>(src + (size_t)r * ld);
+                dv[i] = *reinterpret_cast<const vec_t*>(dyp + (size_t)r * C);
             }
         }
     }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void gn_bwd_fused_kernel(const GroupNormBwd
     for (int t = tid; t < nout * nseg; t += 256) {
         const int o = t % nout, sg = t / nout;
         const int which = o / slab, c = o - which * slab;
-        const int off = (c >> 3) * 16 + which * 8 + (c & 7);
+        const int off = (c / VE) * 16 + which * 8 + (c % VE);
         float acc = 0.f;
         const int r1 = min(RL, (sg + 1) * seg_len);
         for (int r = sg * seg_len; r < r1; ++r) acc += part[(r * slots) * 16 + off];
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256, 1) void gn_bwd_fused_kernel(const GroupNormBwd
     for (int i = 0; i < NVM; ++i) {
         const int r = rl + i * RL;
         if (r < a.HW) {
-            bf16x8 o;
-            if (acc) o = *reinterpret_cast<const bf16x8*>(dst + (size_t)r * ld);
+            vec_t o;
+            if (acc) o = *reinterpret_cast<const vec_t*>(dst + (size_t)r * ld);
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
                 const float xh = ((float)xv[i][e] - mu[e]) * rs[e];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void gn_bwd_fused_kernel(const GroupNormBwd
                 if (acc) g += (float)o[e];
                 o[e] = (bf16)g;
             }
-            *reinterpret_cast<bf16x8*>(dst + (size_t)r * ld) = o;
+            *reinterpret_cast<vec_t*>(dst + (size_t)r * ld) = o;
         }
     }
 }
@@ -359,16 +359,24 @@ int launch_groupnorm_bwd(const GroupNormBwdArgs& a, hipStream_t st) {
     const double act_bytes = (double)a.B * a.HW * C * sizeof(T);
     if constexpr (sizeof(T) == 2) {
         int slab = 0, fslots = 0, fRL = 0, nv = 0;
-        if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv)) {
+        if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv, 8)) {
+            int ve = 8, s4 = 0, sl4 = 0, rl4 = 0, nv4 = 0;  // 8-byte-vector slabs when that doubles a thin grid (as in the forward)
+            static const int ve4_ok = [] { const char* e = getenv("MRISR_GN_VE4"); return e ? atoi(e) : 1; }();
+            if (ve4_ok && a.B * (C / slab) < 512 && gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &s4, &sl4, &rl4, &nv4, 4) &&
+                a.B * (C / s4) > a.B * (C / slab)) {
+                ve = 4; slab = s4; fslots = sl4; fRL = rl4; nv = nv4;
+            }
             const int nslab = C / slab;
             const int xmap = (a.B % 8) == 0 ? 1 : 0;
             ProfScope ps("groupnorm_bwd_fused", 0.0, 3.0 * act_bytes, st);
             const dim3 fg(a.B * nslab);
-            if (nv <= 2) hipLaunchKernelGGL((gn_bwd_fused_kernel<2>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else if (nv <= 4) hipLaunchKernelGGL((gn_bwd_fused_kernel<4>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else if (nv <= 8) hipLaunchKernelGGL((gn_bwd_fused_kernel<8>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else if (nv <= 16) hipLaunchKernelGGL((gn_bwd_fused_kernel<16>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
-            else hipLaunchKernelGGL((gn_bwd_fused_kernel<24>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap);
+#define GNB_GO(NV, VEV) hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, VEV>), fg, dim3(256), 0, st, a, slab, fslots, fRL, nslab, xmap)
+            if (ve == 8) {
+                if (nv <= 2) GNB_GO(2, 8); else if (nv <= 4) GNB_GO(4, 8); else if (nv <= 8) GNB_GO(8, 8); else if (nv <= 16) GNB_GO(16, 8); else GNB_GO(24, 8);
+            } else {
+                if (nv <= 2) GNB_GO(2, 4); else if (nv <= 4) GNB_GO(4, 4); else if (nv <= 8) GNB_GO(8, 4); else if (nv <= 16) GNB_GO(16, 4); else GNB_GO(24, 4);
+            }
+#undef GNB_GO
             MRISR_CHECK_HIP(hipGetLastError());
             return 0;
         }

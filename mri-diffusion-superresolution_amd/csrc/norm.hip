@@ -383,7 +383,8 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
             // (half the channels per slab, twice the workgroups)
             int ve = 8, s4 = 0, sl4 = 0, rl4 = 0, nv4 = 0;
             static const int ve4_ok = [] { const char* e = getenv("MRISR_GN_VE4"); return e ? atoi(e) : 1; }();
-            if (ve4_ok && a.B * (C / slab) < 512 && gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &s4, &sl4, &rl4, &nv4, 4) &&
+            static const int ve4_blocks = [] { const char* e = getenv("MRISR_GN_VE4_BLOCKS"); return e ? atoi(e) : 512; }();
+            if (ve4_ok && a.B * (C / slab) < ve4_blocks && gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &s4, &sl4, &rl4, &nv4, 4) &&
                 a.B * (C / s4) > a.B * (C / slab)) {
                 ve = 4; slab = s4; fslots = sl4; fRL = rl4; nv = nv4;
             }

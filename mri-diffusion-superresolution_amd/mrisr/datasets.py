@@ -255,6 +255,8 @@ class FastMRILazyDataset(Dataset):
         as the reference hands it to PIL, i.e. read as (width, height)."""
         if not items:
             raise ValueError("empty batch")
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise L.MrisrError("slice degradation runs on the GPU (gfx950); there is no CPU fallback")
         out_h, out_w = self.target_size[1], self.target_size[0]
         hr = torch.empty((len(items), out_h, out_w), dtype=torch.float32, device=self.device)
         groups: Dict[Tuple[int, int], List[int]] = {}

@@ -76,7 +76,20 @@ def synthetic_batch(B, device, rank):
     lr_lat = (torch.nn.functional.avg_pool2d(lr, 8).repeat(1, 4, 1, 1) * 0.18215).contiguous()
     ctx = torch.randn((B, 77, 768), device=device, generator=g)
     noise = torch.randn(lr_lat.shape, device=device, generator=g)
-    return lr_lat, ctx, noise
+    return lr_lat, ctx, noise, hr
+
+
+def stub_decode(z):
+    """Stub VAE decoder of SURVEY.md 8d (the real AutoencoderKL is a separate module, not part of the timed path): latents ->
+    [0, 1] grey slice at 8x the size, the way the reference post-processes a decoded sample (res_srdiff.py:113)."""
+    img = torch.nn.functional.interpolate((z / 0.18215).mean(1, keepdim=True), scale_factor=8.0, mode="nearest")
+    return (img / 2 + 0.5).clamp(0, 1)
+
+
+def psnr(a, b):
+    """torchmetrics' PeakSignalNoiseRatio(data_range=1.0) as src/eval/eval.py:15 uses it: 10 log10(1 / mse)."""
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * __import__("math").log10(1.0 / mse)
 
 
 def prof_report(lib):
@@ -85,25 +98,26 @@ def prof_report(lib):
     return json.loads(buf.value.decode()) if n > 0 else {}
 
 
-def cpu_baseline(state_dict_cpu, cfg_oracle, threads):
-    """The oracle (CPU restatement of the reference's diffusers path) on this box's host cores: B=2, 1 warm-up +
-    3 timed sample-steps (bounded sample), extrapolated to slices/s by / 50 steps."""
+def cpu_baseline(state_dict_cpu, cfg_oracle, threads, x_T, ctx, n_steps):
+    """The oracle (CPU restatement of the reference's diffusers path) on this box's host cores: the WHOLE 50-step DDIM loop
+    of ONE slice of the workload - the first slice of rank 0's batch, same x_T and context as the GPU run - so the same
+    bounded sample (about 20-30 s on 16 threads) gives the CPU rate (not extrapolated) and the reference result the GPU
+    outputs are scored against (the "PSNR vs ref" half of the metric)."""
+    from oracle import sampler as osa
+    from oracle import schedulers as osch
     from oracle import unet as ou
     torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(SEED + 7)
-    x = torch.randn((2, 4, LATENT, LATENT), generator=g)
-    ctx = torch.randn((2, 77, 768), generator=g)
+    so = osch.OracleScheduler(timestep_spacing="leading", steps_offset=1)
+    so.set_timesteps(n_steps)
     with torch.no_grad():
-        ou.unet_forward(state_dict_cpu, cfg_oracle, x, torch.tensor(981), ctx)
         t0 = time.perf_counter()
-        n = 3
-        for i in range(n):
-            ou.unet_forward(state_dict_cpu, cfg_oracle, x, torch.tensor(961 - 20 * i), ctx)
+        traj = osa.ddim_sample(ou.OracleUNet(state_dict_cpu, cfg_oracle), x_T, ctx, so)
         dt = time.perf_counter() - t0
-    sample_steps_per_s = 2 * n / dt
-    return {"value": sample_steps_per_s / N_DDIM, "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"oracle UNet fwd fp32, B=2, 1 warm-up + {n} timed sample-steps ({dt:.1f} s), /{N_DDIM} steps (extrapolated)",
-            "sample_steps_per_s": sample_steps_per_s}
+    B = x_T.shape[0]
+    return {"value": B / dt, "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (CPU restatement of the diffusers path, fp32) {n_steps}-step DDIM of {B} slice of the workload, "
+                      f"whole loop, {dt:.1f} s; not extrapolated",
+            "sample_steps_per_s": B * n_steps / dt}, traj[-1]
 
 
 def main():
@@ -151,7 +165,7 @@ def main():
     sched.set_timesteps(args.ddim_steps)
     sampler = mrisr.Sampler(unet, sched, kind="ddim")
     B = args.batch
-    lr_lat, ctx, noise = synthetic_batch(B, dev, rank)
+    lr_lat, ctx, noise, hr = synthetic_batch(B, dev, rank)
     a_T = float(sched.alphas_cumprod[int(sched.timesteps[0])])
     x_T = (lr_lat + (1 - a_T) ** 0.5 * noise).contiguous()  # reference res_srdiff.py:58
     lat = torch.empty_like(x_T)
@@ -183,6 +197,7 @@ def main():
     from mrisr import dist as mdist
     elapsed = mdist.max_over_ranks(elapsed, dev)  # slowest rank's wall time
     finite = bool(torch.isfinite(lat).all())
+    final_slice0 = lat[:1].detach().float().cpu()  # the timed runs' result for slice 0 (the roofline leg below reuses `lat`)
 
     if rank != 0:
         if dist is not None:
@@ -252,9 +267,41 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import unet as ou
         threads = host_threads()
-        log(f"cpu baseline on {threads} threads")
+        # ---- the metric's second half ("PSNR vs ref"): slice 0 of this batch through the CPU oracle for all the DDIM steps,
+        # against (a) the bf16 result of the timed runs and (b) the f32 device engine on the same slice
+        bf16_lat = final_slice0
+        f32_lat = None
+        if args.dtype == "bf16":
+            log("f32 device engine on slice 0 (parity leg)")
+            u32 = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=not args.lora_merged,
+                                             flash_attention=True)
+            u32.load_state_dict(sd)
+            l32 = x_T[:1].clone().contiguous()
+            mrisr.Sampler(u32, sched, kind="ddim").run(l32, ctx[:1], use_graph=False)
+            torch.cuda.synchronize()
+            f32_lat = l32.float().cpu()
+            del u32
+        log(f"cpu oracle: {args.ddim_steps}-step DDIM of slice 0 on {threads} threads")
         sd_cpu = {k: v.detach().float().cpu() for k, v in sd.items()}
-        out["cpu_baseline"] = cpu_baseline(sd_cpu, ou.SD15, threads)
+        out["cpu_baseline"], ref_lat = cpu_baseline(sd_cpu, ou.SD15, threads, x_T[:1].float().cpu(), ctx[:1].float().cpu(),
+                                                    args.ddim_steps)
+        hr01 = (hr[:1].float().cpu() / 2 + 0.5).clamp(0, 1)
+        ref_img = stub_decode(ref_lat)
+
+        def score(z):
+            img = stub_decode(z)
+            return {"rel_l2_latents_vs_oracle": float((z - ref_lat).norm() / ref_lat.norm()),
+                    "rel_l2_image_vs_oracle": float((img - ref_img).norm() / ref_img.norm()),
+                    "psnr_vs_oracle_db": psnr(img, ref_img), "psnr_vs_hr_db": psnr(img, hr01)}
+
+        fid = {"slice": "rank 0, slice 0, stub-decoded [0,1] 256x256", "oracle_psnr_vs_hr_db": psnr(ref_img, hr01),
+               args.dtype: score(bf16_lat)}
+        if f32_lat is not None:
+            fid["f32"] = score(f32_lat)
+        fid["psnr_diff_vs_oracle_db"] = abs(fid[args.dtype]["psnr_vs_hr_db"] - fid["oracle_psnr_vs_hr_db"])
+        out["fidelity"] = fid
+        out["psnr_vs_oracle_db"] = fid[args.dtype]["psnr_vs_oracle_db"]
+        out["rel_l2_f32_vs_oracle"] = (fid.get("f32") or fid[args.dtype])["rel_l2_latents_vs_oracle"]
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,41 @@
+/* mrisr_debug.h - test hooks and tuning tools exported by libmrisr.so.
+ *
+ * NOT part of the drop-in surface (include/mrisr.h): these are process-global switches used by the parity tests
+ * (tests/test_gpu_*.py force split-K, a tile, an older code path, so that every kernel variant is exercised against
+ * the oracle) and by the measurement tools under tools/ (tile sweeps, autotuner statistics).  A product caller never
+ * needs them.  All are no-ops for correctness: every setting selects between implementations of the same arithmetic.
+ */
+#ifndef MRISR_DEBUG_H
+#define MRISR_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GEMM planner overrides (0 restores the planner): a split-K factor for every GEMM that can be split; one kernel
+ * configuration for every GEMM; a specialised kernel (halo conv 41-45, weight-stationary 50-52, row-panel 60+) wherever
+ * it is eligible. */
+void mrisr_debug_force_split(int splitk);
+void mrisr_debug_force_tile(int tile);
+void mrisr_debug_prefer_tile(int tile);
+/* bit flags: 8 = rank-4 LoRA up-projection in the scalar epilogue instead of on the matrix cores; 16 = head-major outputs
+ * stored straight from the accumulator layout instead of through LDS */
+void mrisr_debug_gemm_flags(int flags);
+/* cost-model efficiency of one tile id (only used when the autotuner is off) */
+void mrisr_debug_set_tile_eff(int tile, double eff);
+/* override one entry of the in-process tile table (key as in the MRISR_TUNE_CACHE file) */
+void mrisr_debug_set_tuned(const char* key, int tile, int splitk);
+/* 0: two-kernel GroupNorm everywhere; 1: the one-pass kernel where the geometry allows (default) */
+void mrisr_debug_gn_fused(int on);
+
+/* plan-time autotuner: number of signatures tuned and the time spent; free its scratch operands */
+int mrisr_autotune_stats(int* shapes, double* ms);
+void mrisr_autotune_release(void);
+
+/* micro-benchmark of one GEMM / conv signature on random operands (tools/gemm_sweep.py): average ms over `iters` */
+int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int W, int stride, int ups, int c1, int tile, int splitk,
+                     int iters, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRISR_DEBUG_H */

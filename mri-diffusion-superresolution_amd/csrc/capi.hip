@@ -131,6 +131,14 @@ int mrisr_resshift_forward(const mrisr_tensor* hr, const mrisr_tensor* lr, const
     long long per = 1;
     for (int i = 1; i < hr->ndim; ++i) per *= hr->shape[i];
     const int scalar = timestep->ndim == 0 || timestep->shape[0] == 1;
+    MRISR_REQUIRE(timestep->ndim <= 1 && (scalar || timestep->shape[0] == B), "timesteps: 0-dim, [1] or [B]");
+    {
+        long long nl = 1, nn = 1, no = 1;
+        for (int i = 0; i < lr->ndim; ++i) nl *= lr->shape[i];
+        for (int i = 0; i < noise->ndim; ++i) nn *= noise->shape[i];
+        for (int i = 0; i < out->ndim; ++i) no *= out->shape[i];
+        MRISR_REQUIRE(nl == per * B && nn == per * B && no == per * B, "hr / lr / noise / out must have the same shape");
+    }
     return launch_resshift_forward((const float*)hr->data, (const float*)lr->data, (const float*)noise->data,
                                    alphas_cumprod_dev, (const long long*)timestep->data, scalar, (float*)out->data, B,
                                    per, (hipStream_t)stream);
@@ -149,6 +157,7 @@ struct mrisr_sampler {
     mrisr_model* cnet = nullptr;
     int kind = 0, n_steps = 0, first = 0, last = 0;
     float clip = 0.f;
+    std::vector<float> sigma;  // host copy of each step's noise coefficient (which steps read a step_noise slab)
     DevBuf d_ts, d_coef, d_step, d_curt, d_eps;
     std::vector<std::unique_ptr<DevBuf>> res_bufs;   // ControlNet -> UNet residuals (NHWC, compute dtype)
     std::vector<std::unique_ptr<DevBuf>> intra_bufs;  // adapter features converted once
@@ -184,7 +193,10 @@ int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_ki
     for (int i = 0; i < n_steps; ++i) {
         const long long t = ts[i];
         MRISR_REQUIRE(t >= 0 && t < n_train, "timestep out of range");
-        const double a_t = alphas_cumprod[t];
+        // zero-terminal-SNR tables (rescale_betas_zero_snr, nb ResDif c11:46) end in abar = 0 exactly and "trailing" spacing
+        // samples that entry first: every step divides by sqrt(abar_t) (res_srdiff.py:86), so it is clamped to 2^-24 here
+        // (the reference itself would produce inf)
+        const double a_t = std::max((double)alphas_cumprod[t], 5.9604644775390625e-8);
         if (step_kind == MRISR_STEP_DDIM) {
             // t_prev = t - T/n; alpha_prev = alpha[t_prev] or alpha[0] (set_alpha_to_one=False)
             const long long tp = t - n_train / n_steps;
@@ -211,6 +223,9 @@ int mrisr_sampler_create(mrisr_model* unet, mrisr_model* controlnet, int step_ki
             coef[4 * i + 3] = tp > 0 ? (float)std::sqrt((1.0 - a_p) / (1.0 - a_t) * (1.0 - a_t / a_p)) : 0.f;
         }
     }
+    s->sigma.assign(n_steps, 0.f);
+    for (int i = 0; i < n_steps; ++i)
+        s->sigma[i] = step_kind == MRISR_STEP_DDPM ? coef[8 * i + 4] : (step_kind == MRISR_STEP_RESSHIFT ? coef[4 * i + 3] : 0.f);
     TRY(s->d_ts.reserve(sizeof(long long) * n_steps, false));
     TRY(s->d_coef.reserve(sizeof(float) * coef.size(), false));
     TRY(s->d_step.reserve(16, true));
@@ -253,6 +268,27 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
     const long long n = (long long)B * latents->shape[1] * h * w;
     const int cdt = U.cfg.compute_dtype;
     const int esz = dtype_size(cdt);
+    // every operand the step kernels index is checked against the latents here: the kernels themselves read
+    // lr[i], noise[step * n + i] for i < n without bounds
+    auto numel = [](const mrisr_tensor* t) { long long k = 1; for (int i = 0; i < t->ndim; ++i) k *= t->shape[i]; return k; };
+    MRISR_REQUIRE(latents->shape[1] == U.cfg.in_channels, "latents channels vs the UNet's in_channels");
+    MRISR_REQUIRE(ehs->ndim == 3 && ehs->shape[0] == B && ehs->shape[2] == U.cfg.cross_attention_dim,
+                  "encoder_hidden_states must be [B, L, cross_attention_dim] with the latents' batch");
+    if (lr_latents) MRISR_REQUIRE(lr_latents->dtype == MRISR_F32 && numel(lr_latents) == n, "lr_latents: f32, same shape as latents");
+    if (cond) MRISR_REQUIRE(cond->ndim == 4 && cond->shape[0] == B && cond->shape[2] == 8 * h && cond->shape[3] == 8 * w,
+                            "controlnet_cond must be [B, C, 8h, 8w] with the latents' batch");
+    {
+        int need = 0;  // slabs read: one per step, indexed by the step's position in the schedule, when its sigma != 0
+        for (int i = s->first; i < s->last; ++i)
+            if (s->sigma[i] != 0.f) need = i + 1;
+        if (step_noise) {
+            MRISR_REQUIRE(step_noise->dtype == MRISR_F32 && step_noise->ndim >= 1 && numel(step_noise) % n == 0,
+                          "step_noise: f32, a stack of latents-shaped slabs");
+            MRISR_REQUIRE(numel(step_noise) / n >= need, "step_noise has fewer slabs than the last stochastic step needs");
+        }
+    }
+    for (int i = 0; i < n_intrablock; ++i)
+        MRISR_REQUIRE(intrablock[i].ndim == 4 && intrablock[i].shape[0] == B, "adapter features must carry the latents' batch");
 
     if (use_graph && user == nullptr) {
         // the legacy default stream cannot be captured: run on an internal stream fenced by events
@@ -335,9 +371,18 @@ int mrisr_sampler_run(mrisr_sampler* s, mrisr_tensor* latents, const mrisr_tenso
     if (!use_graph) {
         for (int i = s->first; i < s->last; ++i) TRY(body());
     } else {
-        char key[160];
-        snprintf(key, sizeof(key), "%d,%d,%d,%d,%p,%p,%p,%d", B, h, w, L, latents->data, lr_latents ? lr_latents->data : nullptr,
-                 step_noise ? step_noise->data : nullptr, n_intrablock);
+        // everything the captured launches bake in: geometry, caller pointers, the models' workspace generations (persist /
+        // arena base addresses change when another geometry, a training step or a second sampler re-plans them), this
+        // sampler's own buffers and the feature pointers
+        std::string key;
+        {
+            char kb[256];
+            snprintf(kb, sizeof(kb), "%d,%d,%d,%d,%p,%p,%p,%d,g%llu,%llu,e%p", B, h, w, L, latents->data, lr_latents ? lr_latents->data : nullptr,
+                     step_noise ? step_noise->data : nullptr, n_intrablock, U.ws_gen, s->cnet ? s->cnet->ws_gen : 0ull, s->d_eps.p);
+            key = kb;
+            for (auto& rb : s->res_bufs) { snprintf(kb, sizeof(kb), ",r%p", rb ? rb->p : nullptr); key += kb; }
+            for (auto& f : intra) { snprintf(kb, sizeof(kb), ",f%p", f.data); key += kb; }
+        }
         if (!s->exec || s->graph_key != key) {
             if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
             // workspaces are planned (set_context above), so the captured body performs launches only

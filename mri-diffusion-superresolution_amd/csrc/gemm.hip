@@ -1625,9 +1625,15 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     mrisr_prof_enable_internal(prof_was ? 1 : 0);
     g_tuned[key] = {bt, bs};
-    if (cache_path) {
+    // the on-disk table is READ-ONLY unless MRISR_TUNE_WRITE=1 (building a table to ship): a bench or test run must not modify
+    // a tracked file, and the ranks of a multi-process launch must not append to one file concurrently.  One line per
+    // signature, written with a single O_APPEND write.
+    static const bool cache_write = [] { const char* e = getenv("MRISR_TUNE_WRITE"); return e && e[0] == '1'; }();
+    if (cache_path && cache_write) {
         if (FILE* f = fopen(cache_path, "a")) {
-            fprintf(f, "%s\t%d\t%d\n", key, bt, bs);
+            char line[256];
+            const int len = snprintf(line, sizeof(line), "%s\t%d\t%d\n", key, bt, bs);
+            if (len > 0) (void)fwrite(line, 1, (size_t)len, f);
             fclose(f);
         }
     }

@@ -59,6 +59,8 @@ struct Model {
     Arena arena;
     DevBuf persist;
     std::string ws_key;
+    unsigned long long ws_gen = 0;  // bumped whenever persist / arena are re-planned or reallocated: captured graphs that
+                                    // baked the old addresses in must be re-captured (mrisr_sampler_run keys on it)
     int ws_B = 0, ws_h = 0, ws_w = 0, ctx_len = 0, ctx_pad = 0;
     std::vector<HeadBuf> heads;
     void* ctx_rows = nullptr;

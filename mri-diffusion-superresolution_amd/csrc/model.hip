@@ -399,6 +399,7 @@ static int plan_t(Model& m, int B, int h, int w, int L, hipStream_t st) {
     const mrisr_unet_cfg& c = m.cfg;
     constexpr int BK = 128 / (int)sizeof(T);
     const bool flash = c.flash_attention && sizeof(T) == 2;
+    ++m.ws_gen;
     m.heads.clear();
     m.ws_B = B; m.ws_h = h; m.ws_w = w; m.ctx_len = L;
     m.ctx_pad = round_up(L, 64);

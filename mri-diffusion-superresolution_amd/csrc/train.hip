@@ -835,6 +835,7 @@ static int train_step_t(Model& m, const mrisr_tensor& sample, const long long* t
                         const mrisr_tensor* pred_out, hipStream_t st) {
     if (m.train_ws_key != m.ws_key) {
         // dry pass of forward + backward sizes the arena exactly
+        ++m.ws_gen;  // the arena may be reallocated below
         m.arena.dry = true;
         m.arena.reset();
         m.arena.peak = 0;

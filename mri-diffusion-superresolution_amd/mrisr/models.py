@@ -132,7 +132,13 @@ class _DeviceModel:
         return self
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        return dict(self._params)
+        sd = dict(self._params)
+        tr = getattr(self, "_trainer", None)
+        tr = tr() if tr is not None else None
+        if tr is not None:  # a LoRATrainer owns the adapters now: report their trained values, not the loaded ones
+            for k, v in tr.state_dict().items():
+                sd[k] = v.to(sd[k].dtype) if k in sd else v
+        return sd
 
     def parameters(self):
         return iter(self._params.values())
@@ -141,6 +147,11 @@ class _DeviceModel:
         """diffusers key names; peft LoRA keys ``<module>.lora_{A,B}.default.weight``."""
         fn = L.lib().mrisr_model_set_param
         for k, v in sd.items():
+            # LoRA keys in any of peft's / diffusers' on-disk forms are accepted (adapter name stripped, "base_model.model." or
+            # "unet." prefix); everything else must be a diffusers UNet key as is
+            if ".lora_A." in k or ".lora_B." in k:
+                from .train import lora_keys_from_disk
+                k = next(iter(lora_keys_from_disk({k: None})))
             self._params[k] = v
             L.push_param(fn, self._h, k, v)
         L.check(L.lib().mrisr_model_set_lora_scale(self._h, C.c_float(self.lora_scale)))

@@ -27,6 +27,14 @@ def get_res_shifting_latents(hr_latents, lr_latents, timesteps, scheduler, noise
         noise = torch.randn_like(hr_latents)
     ac = scheduler.alphas_cumprod.to(device=dev, dtype=torch.float32).contiguous()
     t = torch.as_tensor(timesteps).to(device=dev, dtype=torch.int64).contiguous()
+    # the reference indexes ``alphas_cumprod[timesteps]`` and broadcasts [B,1,1,1] (:13-19): a wrong length or an index outside
+    # the table is an error there; the kernel reads ac[t[b]] unchecked, so both are checked here
+    if t.ndim > 1 or (t.ndim == 1 and t.numel() not in (1, hr_latents.shape[0])):
+        raise RuntimeError(f"timesteps of shape {tuple(t.shape)} do not broadcast against a batch of {hr_latents.shape[0]}")
+    if t.numel() and (int(t.min()) < -ac.numel() or int(t.max()) >= ac.numel()):
+        raise IndexError(f"timestep out of range for an alphas_cumprod table of {ac.numel()} entries")
+    if t.numel() and int(t.min()) < 0:
+        t = torch.where(t < 0, t + ac.numel(), t)  # torch indexing semantics for negative indices
     hr, lr, nz = (x.to(torch.float32).contiguous() for x in (hr_latents, lr_latents, noise))
     out = torch.empty_like(hr)
     t_hr, t_lr, t_nz, t_t, t_out = (L.as_tensor(x) for x in (hr, lr, nz, t, out))

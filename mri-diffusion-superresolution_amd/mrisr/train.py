@@ -24,12 +24,44 @@ from . import _lib as L
 from .dist import all_reduce_sum_
 
 
-def cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
-    """diffusers ``get_cosine_schedule_with_warmup`` (half cosine, num_cycles = 0.5), as the reference's config uses."""
+def cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int, num_cycles: float = 0.5) -> float:
+    """diffusers ``get_cosine_schedule_with_warmup`` (``lr_scheduler_name: "cosine"``, nb ResDif c11:25: half a cosine, since
+    ``get_scheduler`` hands ``num_cycles`` only to the with-restarts variant).  Like diffusers the progress is NOT clamped:
+    past ``total_steps`` the multiplier follows the cosine on (and is floored at 0)."""
     if step < warmup_steps:
         return base_lr * step / max(1, warmup_steps)
     p = (step - warmup_steps) / max(1, total_steps - warmup_steps)
-    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * min(1.0, p))))
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * num_cycles * 2.0 * p)))
+
+
+# LoRA checkpoint key forms.  In memory (and in ``state_dict()``) the adapters carry peft's keys with the adapter name,
+# ``<module>.lora_A.default.weight``.  On disk peft writes them WITHOUT the adapter name under a ``base_model.model.`` prefix
+# (``get_peft_model_state_dict`` / ``set_peft_model_state_dict``), diffusers' LoRA loaders use ``unet.<module>.lora_A.weight``.
+_KEY_PREFIX = {"peft": "base_model.model.", "diffusers": "unet.", "memory": ""}
+
+
+def lora_keys_to_disk(sd: Dict[str, torch.Tensor], key_format: str = "peft") -> Dict[str, torch.Tensor]:
+    if key_format not in _KEY_PREFIX:
+        raise ValueError(f"key_format must be one of {sorted(_KEY_PREFIX)}")
+    if key_format == "memory":
+        return dict(sd)
+    pre = _KEY_PREFIX[key_format]
+    return {pre + k.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): v for k, v in sd.items()}
+
+
+def lora_keys_from_disk(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Any of the three forms -> the in-memory peft keys (other keys pass through)."""
+    out = {}
+    for k, v in sd.items():
+        for pre in ("base_model.model.", "unet."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+                break
+        for ab in ("lora_A", "lora_B"):
+            if k.endswith(f".{ab}.weight"):
+                k = k[:-len(f".{ab}.weight")] + f".{ab}.default.weight"
+        out[k] = v
+    return out
 
 
 class _FlatAdamW:
@@ -77,31 +109,60 @@ class _FlatAdamW:
         self._last_sumsq = ss
 
     # ---- EMA of the trainable parameters (diffusers EMAModel: use_ema in the reference's training config) ----
-    def ema_step(self, decay: float = 0.9999):
-        if getattr(self, "ema", None) is None:
-            self.ema = self.theta.clone()
-            return
-        L.check(L.lib().mrisr_optim_ema(C.c_void_p(self.ema.data_ptr()), C.c_void_p(self.theta.data_ptr()), C.c_int64(self.theta.numel()),
-                                        C.c_float(decay), L.stream_ptr()))
+    def ema_init(self):
+        """EMAModel(parameters): the shadow starts as a copy of the parameters at construction time."""
+        self.ema = self.theta.clone()
+        self.ema_steps = 0
 
-    # ---- checkpoints: parameters under their state-dict keys (safetensors, loadable by peft / the reference module), the
-    #      optimiser state as flat vectors ----
-    def save_checkpoint(self, path: str, use_ema: bool = False):
+    @staticmethod
+    def ema_decay_at(optimization_step: int, decay: float = 0.9999, min_decay: float = 0.0, update_after_step: int = 0,
+                     use_ema_warmup: bool = False, inv_gamma: float = 1.0, power: float = 2.0 / 3.0) -> float:
+        """diffusers ``EMAModel.get_decay``: 0 until ``update_after_step``, then (1+s)/(10+s) (or the warm-up curve
+        1-(1+s/inv_gamma)^-power), clamped to [min_decay, decay]."""
+        step = max(0, optimization_step - update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = 1.0 - (1.0 + step / inv_gamma) ** -power if use_ema_warmup else (1.0 + step) / (10.0 + step)
+        return max(min(cur, decay), min_decay)
+
+    def ema_step(self, decay: float = 0.9999, **schedule):
+        """One ``EMAModel.step``: shadow -= (1 - d) (shadow - theta) with d = ``ema_decay_at(step count)``; ``decay`` is the
+        ceiling of the schedule, as in diffusers (NOT a constant rate)."""
+        if getattr(self, "ema", None) is None:
+            self.ema_init()
+        self.ema_steps = getattr(self, "ema_steps", 0) + 1
+        d = self.ema_decay_at(self.ema_steps, decay, **schedule)
+        L.check(L.lib().mrisr_optim_ema(C.c_void_p(self.ema.data_ptr()), C.c_void_p(self.theta.data_ptr()), C.c_int64(self.theta.numel()),
+                                        C.c_float(d), L.stream_ptr()))
+        return d
+
+    # ---- checkpoints: parameters as a safetensors file in peft's ON-DISK key form by default (adapter name stripped,
+    #      ``base_model.model.`` prefix: what ``set_peft_model_state_dict`` / ``PeftModel.from_pretrained`` read), or diffusers'
+    #      ``unet.`` form; conv parameters of the T2I-Adapter keep the reference module's own keys.  Optimiser state as flat
+    #      vectors next to it. ----
+    def save_checkpoint(self, path: str, use_ema: bool = False, key_format: str = "peft"):
         from safetensors.torch import save_file
         flat = self.ema if (use_ema and getattr(self, "ema", None) is not None) else self.theta
-        save_file({k: v.contiguous().cpu() for k, v in self._views(flat).items()}, path)
+        sd = {k: v.contiguous().cpu() for k, v in self._views(flat).items()}
+        save_file(lora_keys_to_disk(sd, key_format if any(".lora_" in k for k in sd) else "memory"), path)
         torch.save({"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                    "ema": None if getattr(self, "ema", None) is None else self.ema.cpu()}, path + ".optim.pt")
+                    "ema": None if getattr(self, "ema", None) is None else self.ema.cpu(),
+                    "ema_steps": getattr(self, "ema_steps", 0)}, path + ".optim.pt")
 
     def load_checkpoint(self, path: str):
         from safetensors.torch import load_file
-        self.load_state_dict(load_file(path))
+        sd = lora_keys_from_disk(load_file(path))
+        missing = [k for k in self._views(self.theta) if k not in sd]
+        if missing:
+            raise KeyError(f"checkpoint {path} lacks {len(missing)} trainable tensors, e.g. {missing[0]}")
+        self.load_state_dict(sd)
         if os.path.exists(path + ".optim.pt"):
             st = torch.load(path + ".optim.pt", map_location="cpu")
             self.step_count = int(st["step"])
             self.exp_avg.copy_(st["exp_avg"])
             self.exp_avg_sq.copy_(st["exp_avg_sq"])
             self.ema = None if st["ema"] is None else st["ema"].to(self.theta.device)
+            self.ema_steps = int(st.get("ema_steps", 0))
 
     def grad_norm(self, world: int = 1) -> float:
         """Global L2 norm of the (averaged) gradient as used by the last ``optimizer_step``."""
@@ -133,6 +194,8 @@ class LoRATrainer(_FlatAdamW):
             self.layout.append((key.value.decode(), int(off.value), (int(shp[0]), int(shp[1]))))
         L.check(lib.mrisr_train_bind(unet._h, C.c_void_p(self.theta.data_ptr()), C.c_void_p(self.grad.data_ptr()), 1,
                                      L.stream_ptr()))
+        import weakref
+        unet._trainer = weakref.ref(self)  # unet.state_dict() reads the adapters' CURRENT values from this trainer
 
     # ---- views ----
     def _views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -147,7 +210,7 @@ class LoRATrainer(_FlatAdamW):
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         views = self._views(self.theta)
-        for k, v in sd.items():
+        for k, v in lora_keys_from_disk(sd).items():
             if k in views:
                 views[k].copy_(v.to(self.theta.device, torch.float32))
         L.check(L.lib().mrisr_train_refresh(self.unet._h, L.stream_ptr()))

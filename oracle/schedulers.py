@@ -23,6 +23,18 @@ def make_betas(num_train_timesteps: int = 1000, beta_start: float = 0.00085, bet
     return b.numpy()
 
 
+def rescale_zero_terminal_snr(betas: np.ndarray) -> np.ndarray:
+    """``rescale_betas_zero_snr=True`` (nb ResDif c11:46): Algorithm 1 of Lin et al. 2023, as diffusers applies it to the
+    float32 beta table - sqrt(abar) shifted to end at exactly 0 and rescaled to keep its first entry."""
+    b = torch.from_numpy(betas)
+    s = torch.cumprod(1.0 - b, dim=0).sqrt()
+    s0, sT = s[0].clone(), s[-1].clone()
+    s = (s - sT) * (s0 / (s0 - sT))
+    abar = s ** 2
+    alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+    return (1.0 - alphas).numpy()
+
+
 def alphas_cumprod_from_betas(betas: np.ndarray) -> np.ndarray:
     return torch.cumprod(1.0 - torch.from_numpy(betas), dim=0).numpy()
 
@@ -44,9 +56,11 @@ class OracleScheduler:
     """The three members the reference uses, plus ddim_step for BASELINE's 50-step DDIM."""
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
-                 beta_schedule="scaled_linear", timestep_spacing="leading", steps_offset=0):
+                 beta_schedule="scaled_linear", timestep_spacing="leading", steps_offset=0, rescale_betas_zero_snr=False):
         self.num_train_timesteps = num_train_timesteps
         self.betas = make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        if rescale_betas_zero_snr:
+            self.betas = rescale_zero_terminal_snr(self.betas)
         self.alphas_cumprod = torch.from_numpy(alphas_cumprod_from_betas(self.betas))
         self.timestep_spacing, self.steps_offset = timestep_spacing, steps_offset
         self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1)

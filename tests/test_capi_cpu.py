@@ -23,6 +23,15 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_lib.EXPORTS) <= declared
     assert b"gfx950" in lib.mrisr_version()
+    # ... and nothing is exported behind the headers' back: every mrisr_* symbol of the library is declared either in the
+    # drop-in header or in the test-hook header (include/mrisr_debug.h)
+    import subprocess
+    dbg = open(os.path.join(ROOT, "include", "mrisr_debug.h")).read()
+    declared_dbg = set(re.findall(r"^(?:int|void)\s+(mrisr_[a-z0-9_]+)\(", dbg, flags=re.M))
+    assert not (declared & declared_dbg)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("mrisr_")}
+    assert exported == declared | declared_dbg, sorted(exported ^ (declared | declared_dbg))
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -57,6 +66,36 @@ def test_scheduler_tables_match_oracle():
             assert torch.equal(a.timesteps, b.timesteps)
     lin = mrisr.DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear")  # MNIST notebook c5:1-9
     assert lin.alphas_cumprod[0].item() == pytest.approx(1 - 1e-4)
+
+
+def test_scheduler_reference_training_config_zero_terminal_snr():
+    """The reference's training config (nb ResDif c11:44-46): epsilon prediction, "trailing" spacing,
+    rescale_betas_zero_snr=True.  Lin et al. 2023 Alg. 1 properties of the table, product == oracle bit for bit, and no
+    option is swallowed silently any more."""
+    import mrisr
+    from oracle import schedulers as osch
+    kw = dict(prediction_type="epsilon", timestep_spacing="trailing", rescale_betas_zero_snr=True)
+    a = mrisr.DDPMScheduler(**kw)
+    b = osch.OracleScheduler(timestep_spacing="trailing", rescale_betas_zero_snr=True)
+    plain = mrisr.DDPMScheduler()
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod) and torch.equal(a.betas, torch.from_numpy(b.betas))
+    ac, ac0 = a.alphas_cumprod.double(), plain.alphas_cumprod.double()
+    assert abs(float(ac[-1])) < 1e-10 and float(a.betas[-1]) == 1.0      # terminal SNR exactly zero
+    assert float(ac[0]) == pytest.approx(float(ac0[0]), rel=1e-6)             # first entry kept
+    # sqrt(abar) is an affine map of the original table: s' = (s - s_T) * s_0 / (s_0 - s_T)
+    s0, sT = ac0[0].sqrt(), ac0[-1].sqrt()
+    assert torch.allclose(ac.sqrt(), (ac0.sqrt() - sT) * (s0 / (s0 - sT)), atol=2e-6)
+    a.set_timesteps(20)
+    assert int(a.timesteps[0]) == 999 and float(a.alphas_cumprod[int(a.timesteps[0])]) < 1e-10   # the t the C sampler clamps
+    assert mrisr.DDIMScheduler(rescale_betas_zero_snr=True).rescale_betas_zero_snr
+    # defaults of the fused step may be spelled out; anything else is refused, unknown keys too
+    mrisr.DDPMScheduler(variance_type="fixed_small", clip_sample=False, thresholding=False)
+    mrisr.DDIMScheduler(set_alpha_to_one=False)
+    for bad in (dict(variance_type="learned_range"), dict(clip_sample=True), dict(set_alpha_to_one=True), dict(thresholding=True),
+                dict(trained_betas=[0.1, 0.2]), dict(prediction_type="v_prediction"), dict(timestep_spacing="linspace"),
+                dict(beta_schedule="squaredcos_cap_v2"), dict(no_such_option=1)):
+        with pytest.raises(ValueError):
+            mrisr.DDPMScheduler(**bad)
 
 
 def test_config_mirror():

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -148,3 +149,33 @@ def test_all_reduce_is_identity_without_process_group():
     assert abs(cosine_lr(500, 1e-4, 500, 10000) - 1e-4) < 1e-12
     assert abs(cosine_lr(5250, 1e-4, 500, 10000) - 5e-5) < 1e-9
     assert cosine_lr(10000, 1e-4, 500, 10000) < 1e-12
+    # like diffusers the progress is not clamped: one full period later the multiplier is back at 1
+    assert abs(cosine_lr(500 + 2 * 9500, 1e-4, 500, 10000) - 1e-4) < 1e-12
+    assert cosine_lr(12000, 1e-4, 500, 10000) > 0.0
+
+
+def test_lora_checkpoint_key_forms_and_ema_schedule():
+    """peft writes adapters without the adapter name under "base_model.model.", diffusers under "unet."; both load back to
+    the in-memory "<module>.lora_A.default.weight" keys.  EMA decay follows diffusers EMAModel.get_decay."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mri-diffusion-superresolution_amd"))
+    from mrisr.train import _FlatAdamW, lora_keys_from_disk, lora_keys_to_disk
+    mem = {"down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.lora_A.default.weight": torch.zeros(4, 8),
+           "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.lora_B.default.weight": torch.ones(8, 4)}
+    peft = lora_keys_to_disk(mem, "peft")
+    assert sorted(peft) == ["base_model.model.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.lora_B.weight",
+                            "base_model.model.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.lora_A.weight"]
+    dif = lora_keys_to_disk(mem, "diffusers")
+    assert all(k.startswith("unet.") and ".default." not in k for k in dif)
+    for disk in (peft, dif, lora_keys_to_disk(mem, "memory"), mem):
+        back = lora_keys_from_disk(disk)
+        assert set(back) == set(mem) and all(torch.equal(back[k], mem[k]) for k in mem)
+    assert lora_keys_from_disk({"conv_in.weight": 1}) == {"conv_in.weight": 1}
+    with pytest.raises(ValueError):
+        lora_keys_to_disk(mem, "hf")
+    d = _FlatAdamW.ema_decay_at
+    assert d(1) == 0.0 and abs(d(2) - 2 / 11) < 1e-15 and abs(d(101) - 101 / 110) < 1e-15 and d(10 ** 7) == 0.9999
+    assert d(5, update_after_step=10) == 0.0 and d(12, update_after_step=10) == 2 / 11
+    assert abs(d(11, use_ema_warmup=True, inv_gamma=1.0, power=2 / 3) - (1 - 11 ** (-2 / 3))) < 1e-15
+    assert d(3, min_decay=0.5) == 0.5

@@ -350,20 +350,46 @@ def test_ema_and_checkpoint_roundtrip(tiny, tmp_path):
         return mrisr.LoRATrainer(net, lr=1e-3)
 
     tr = fresh()
-    tr.ema_step(0.9)                       # first call seeds the average with the parameters
-    tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
     theta0 = torch.cat([lora[k].reshape(-1) for k, _, _ in tr.layout]).cuda()
-    tr.ema_step(0.9)
-    assert rel(tr.ema, 0.9 * theta0 + 0.1 * tr.theta) < 1e-6
+    tr.ema_init()                          # EMAModel(parameters): shadow = the parameters at construction
+    tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    assert tr.ema_step(0.9) == 0.0         # diffusers EMAModel.get_decay: optimisation step 1 -> decay 0 -> shadow = theta
+    assert rel(tr.ema, tr.theta) < 1e-7
+    theta1 = tr.theta.clone()
+    tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    d = tr.ema_step(0.9)                   # step 2 -> (1 + 1) / (10 + 1)
+    assert abs(d - 2.0 / 11.0) < 1e-12
+    assert rel(tr.ema, d * theta1 + (1 - d) * tr.theta) < 1e-6
+    for _ in range(98):
+        tr.ema_steps += 1
+    assert tr.ema_decay_at(tr.ema_steps + 1, 0.9) == 0.9   # ... rising to the ceiling
+    assert not torch.equal(theta0, tr.theta)
+    # unet.state_dict() reports the TRAINED adapters (it used to return the tensors handed to load_state_dict)
+    usd = tr.unet.state_dict()
+    k0 = tr.layout[0][0]
+    assert torch.equal(usd[k0].float().cpu(), tr.state_dict()[k0].cpu()) and not torch.equal(usd[k0].float().cpu(), lora[k0])
     path = str(tmp_path / "lora.safetensors")
-    tr.save_checkpoint(path)
+    tr.save_checkpoint(path)               # peft's on-disk form: adapter name stripped, "base_model.model." prefix
     sd = load_file(path)
-    assert set(sd) == set(lora) and all(torch.equal(sd[k], tr.state_dict()[k].cpu()) for k in sd)
+    want = {"base_model.model." + k.replace(".default.", "."): k for k in lora}
+    assert set(sd) == set(want) and all(torch.equal(sd[k], tr.state_dict()[want[k]].cpu()) for k in sd)
+    tr.save_checkpoint(str(tmp_path / "d.safetensors"), key_format="diffusers")
+    assert set(load_file(str(tmp_path / "d.safetensors"))) == {"unet." + k.replace(".default.", ".") for k in lora}
+    n_before = tr.step_count
     tr.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
     tr2 = fresh()
     tr2.load_checkpoint(path)
-    assert tr2.step_count == 1
+    assert tr2.step_count == n_before and tr2.ema_steps == tr.ema_steps
     tr2.step(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
     assert rel(tr2.theta, tr.theta) < 1e-6
+    # a model built straight from the on-disk keys (either form) equals the trained one
+    net3 = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+    net3.load_state_dict({**up, **load_file(str(tmp_path / "d.safetensors"))})
+    assert set(net3.state_dict()) == set(up) | set(lora)
+    with pytest.raises(KeyError):
+        bad = dict(sd); bad.pop(next(iter(bad)))
+        from safetensors.torch import save_file
+        save_file(bad, str(tmp_path / "bad.safetensors"))
+        fresh().load_checkpoint(str(tmp_path / "bad.safetensors"))
     tr.save_checkpoint(str(tmp_path / "ema.safetensors"), use_ema=True)
     assert rel(torch.cat([load_file(str(tmp_path / "ema.safetensors"))[k].reshape(-1) for k, _, _ in tr.layout]), tr.ema) < 1e-7

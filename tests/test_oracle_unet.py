@@ -163,3 +163,40 @@ def test_scheduler_tables_and_ddim():
     assert torch.allclose(xp, ac[tp].sqrt() * x0 + (1 - ac[tp]).sqrt() * eps, atol=1e-5)
     cx, ce = s.ddim_coeffs(t)
     assert torch.allclose(xp, cx * x + ce * eps, atol=1e-5)
+
+
+@pytest.mark.parametrize("heads,d,nq,nk", [(8, 40, 64, 64), (8, 80, 16, 77), (8, 160, 16, 16), (2, 8, 5, 3)])
+def test_attention_matches_scaled_dot_product_attention(heads, d, nq, nk):
+    """the oracle's hand-rolled softmax(q k^T / sqrt(d)) v (oracle/unet.py `attention`, which restates diffusers'
+    AttnProcessor) against torch's own F.scaled_dot_product_attention on the same projections - self-attention and the
+    77-token cross-attention shape, the three SD-1.5 head sizes, with and without LoRA on the projections."""
+    import torch.nn.functional as F
+    C = heads * d
+    g = torch.Generator().manual_seed(7 + d)
+    p = {}
+    for n, cin in (("to_q", C), ("to_k", C if nk == nq else 96), ("to_v", C if nk == nq else 96)):
+        p[f"a.{n}.weight"] = torch.randn((C, cin), generator=g) / math.sqrt(cin)
+    p["a.to_out.0.weight"] = torch.randn((C, C), generator=g) / math.sqrt(C)
+    p["a.to_out.0.bias"] = torch.randn((C,), generator=g)
+    x = torch.randn((2, nq, C), generator=g)
+    ctx = x if nk == nq else torch.randn((2, nk, 96), generator=g)
+    for with_lora in (False, True):
+        if with_lora:
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                cin = p[f"a.{n}.weight"].shape[1]
+                p[f"a.{n}.lora_A.default.weight"] = torch.randn((4, cin), generator=g) / math.sqrt(cin)
+                p[f"a.{n}.lora_B.default.weight"] = 0.1 * torch.randn((C, 4), generator=g)
+        got = ou.attention(p, "a", x, ctx, heads, 0.5)
+
+        def lin(n, t):
+            y = F.linear(t, p[f"a.{n}.weight"], p.get(f"a.{n}.bias"))
+            if with_lora:  # peft: y += scale * B(A(x))
+                y = y + 0.5 * F.linear(F.linear(t, p[f"a.{n}.lora_A.default.weight"]), p[f"a.{n}.lora_B.default.weight"])
+            return y
+
+        q = lin("to_q", x).view(2, nq, heads, d).transpose(1, 2)
+        k = lin("to_k", ctx).view(2, nk, heads, d).transpose(1, 2)
+        v = lin("to_v", ctx).view(2, nk, heads, d).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+        want = lin("to_out.0", o.transpose(1, 2).reshape(2, nq, C))
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), float((got - want).abs().max())

@@ -267,6 +267,10 @@ int mrisr_op_conv3x3(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, co
                      mrisr_tensor* y_nhwc, void* stream);
 int mrisr_op_linear(const mrisr_tensor* x_rows, const float* w_dev, const float* bias_dev, int n, int act,
                     int splitk, int tile, mrisr_tensor* y_rows, void* stream);
+/* y = LayerNorm(x; gamma, beta, eps 1e-5) W^T + bias with the normalisation as a prologue of the row-panel GEMM kernel (bf16;
+ * K = 320 or 640, n % 16 == 0) - the form the transformer blocks use for norm1/2/3 -> to_q|k|v / to_q / ff.net.0.proj */
+int mrisr_op_ln_linear(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, const float* w_dev,
+                       const float* bias_dev, int n, int act, mrisr_tensor* y_rows, void* stream);
 int mrisr_op_groupnorm(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, const float* gamma_dev,
                        const float* beta_dev, int groups, float eps, int silu, mrisr_tensor* y_nhwc, void* stream);
 int mrisr_op_layernorm(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, float eps,

@@ -1005,6 +1005,37 @@ int mrisr_op_linear(const mrisr_tensor* x, const float* w_dev, const float* bias
     API_END
 }
 
+int mrisr_op_ln_linear(const mrisr_tensor* x, const float* gamma_dev, const float* beta_dev, const float* w_dev, const float* bias_dev,
+                       int n, int act, mrisr_tensor* y, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    TRY(gemm_prepare());
+    MRISR_REQUIRE(x->ndim == 2 && y && y->ndim == 2 && y->dtype == x->dtype && x->dtype == MRISR_BF16, "bf16 rows in/out");
+    MRISR_REQUIRE(gamma_dev && beta_dev && w_dev, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)x->shape[0], K = (int)x->shape[1];
+    DevBuf wp, bp;
+    TRY(wp.reserve((size_t)n * K * 2, false));
+    const bool geglu = act == ACT_GEGLU;
+    TRY(launch_pack_rows<bf16>(w_dev, n, K, wp.p, K, 0, 0, geglu ? 1 : 0, n / 2, 1.0f, st));
+    const float* bias = bias_dev;
+    if (geglu && bias_dev) {
+        TRY(bp.reserve((size_t)n * sizeof(float), false));
+        TRY(launch_pack_bias_geglu(bias_dev, static_cast<float*>(bp.p), n / 2, st));
+        bias = static_cast<const float*>(bp.p);
+    }
+    GemmArgs g;
+    g.a0 = x->data; g.c0 = K; g.lda0 = K; g.w = wp.p; g.M = M; g.N = n; g.K = K; g.bias = bias; g.act = act;
+    g.out = y->data; g.ldo = (int)y->shape[1];
+    MRISR_REQUIRE(gemm_rp_tile(g) != 0, "LayerNorm prologue: the row-panel kernel does not take this shape (K = 320 / 640, N % 16 == 0)");
+    g.ln_gamma = gamma_dev; g.ln_beta = beta_dev; g.ln_eps = 1e-5f;
+    TRY(gemm_choose(g, true));
+    TRY(launch_gemm<bf16>(g, st));
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+    API_END
+}
+
 int mrisr_op_groupnorm(const mrisr_tensor* x, const mrisr_tensor* x2, const float* gamma_dev, const float* beta_dev,
                        int groups, float eps, int silu, mrisr_tensor* y, void* stream) {
     API_BEGIN

@@ -129,6 +129,11 @@ struct GemmArgs {
     const void* lora_a = nullptr;
     int lora_R = 0;
     float* lora_zout = nullptr;
+    // row-panel kernel (tiles 60+): optional LayerNorm prologue on the A rows (statistics over K, affine from these vectors)
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    float ln_eps = 1e-5f;
+    int no_rp = 0;    // the caller's operand forms rule the row-panel kernel out (e.g. LoRA of a rank it does not fuse)
     int group_m = 1;  // M tiles per group of the tile order (set by the launchers: auto_group_m; MRISR_GROUP_M)
     int dbg = 0;  // cross-check switches (mrisr_debug_gemm_flags): 8 scalar LoRA up-projection, 16 unstaged head-major stores
 };
@@ -138,6 +143,7 @@ template <typename T> int launch_splitk_reduce(const GemmArgs& g, hipStream_t st
 const void* zero_page();  // >= 256 bytes of device zeros, valid after init_zero_page()
 int init_zero_page();
 int gemm_prepare();
+int gemm_rp_tile(const GemmArgs& g);  // row-panel kernel id for this (plain, short-K, bf16) GEMM, 0 if it is not eligible
 int gemm_choose(GemmArgs& g, bool is_bf16);  // sets g.tile / g.splitk (autotuned per signature for bf16)  // set launch attributes of every GEMM instantiation (call before graph capture)
 
 // ---------------------------------------------------------------------------------------------

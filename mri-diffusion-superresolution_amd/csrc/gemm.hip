@@ -22,11 +22,12 @@
 namespace mrisr {
 
 static void* g_zero_page = nullptr;
+static constexpr size_t kZeroPageBytes = 128 * 1024;  // also the all-zero bias vector of bias-free row-panel launches (N <= 32,768)
 const void* zero_page() { return g_zero_page; }
 int init_zero_page() {
     if (g_zero_page) return 0;
-    MRISR_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
-    MRISR_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+    MRISR_CHECK_HIP(hipMalloc(&g_zero_page, kZeroPageBytes));
+    MRISR_CHECK_HIP(hipMemset(g_zero_page, 0, kZeroPageBytes));
     return 0;
 }
 
@@ -89,14 +90,21 @@ __device__ __forceinline__ int exchange_tokens4(const float* v, unsigned& w0, un
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n0, float* v, const float* vg, const float* zl = nullptr,
                                           T* lds_dst = nullptr, bool resid_later = false, bool mfma_lanes = true, T* lds_t = nullptr,
-                                          int ml = 0, int nl = 0, int tpitch = 0) {
+                                          int ml = 0, int nl = 0, int tpitch = 0, const float* pb = nullptr, const float* pbg = nullptr) {
+    // pb / pbg: the column operands of these 4 columns (bias [+ the time-embedding row vector when one row serves every output
+    // row]; GEGLU: u and gate bias), preloaded by preload_cols() BEFORE the caller's fragment loop.  Loading them here - inside
+    // the caller's per-fragment `if (m < M && n < N)` - put one global-load round trip in front of every fragment's math: 8-20
+    // SERIAL L2 latencies per workgroup, which was most of a short-K projection's run time (tools/probes/rp_probe2.sh).
     const float alpha = g.alpha;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.act == ACT_GEGLU) {
         // weight rows are interleaved in blocks of 16: [u0..u15 | g0..g15 | u16.. ]; n0 indexes the u block
         // in the interleaved space, the gate block sits 16 columns later; output column = compacted index.
         float bu[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
-        if (g.bias) {
+        if (pb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bu[r] = pb[r]; bg[r] = pbg[r]; }
+        } else if (g.bias) {
             load4<float>(g.bias + n0, bu);
             load4<float>(g.bias + n0 + 16, bg);
         }
@@ -107,7 +115,12 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
         store4<T>(o, v);
         return;
     }
-    if (g.bias) load4<float>(g.bias + n0, b4);
+    if (pb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = pb[r];
+    } else if (g.bias) {
+        load4<float>(g.bias + n0, b4);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = v[r] * alpha + b4[r];
     if (g.lora_z || zl) {
@@ -132,7 +145,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
             }
         }
     }
-    if (g.rowvec) {
+    if (g.rowvec && !(pb && g.rowvec_div >= g.M)) {  // (folded into pb when row 0 serves every output row: scalar timestep)
         float t4[4];
         load4<float>(g.rowvec + (size_t)(m / g.rowvec_div) * g.rowvec_ld + n0, t4);
 #pragma unroll
@@ -193,6 +206,22 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int z, int m, int n
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[(size_t)r * g.npad] = from_f32<T>(v[r]);
         }
+    }
+}
+
+// Column operands of a lane's NFR column fragments (fragment i covers columns nbase + 16 i .. + 3), all loads issued back to
+// back ahead of the epilogue loop (clamped addresses instead of a per-lane branch: columns past N are never stored).
+template <int NFR>
+__device__ __forceinline__ void preload_cols(const GemmArgs& g, int nbase, float (&pb)[NFR][4]) {
+    const bool fold = g.rowvec && g.rowvec_div >= g.M;
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) {
+        const int n = min(nbase + i * 16, g.N - 4);
+        float b[4] = {0.f, 0.f, 0.f, 0.f}, t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) load4<float>(g.bias + n, b);
+        if (fold) load4<float>(g.rowvec + n, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb[i][r] = b[r] + t[r];
     }
 }
 
@@ -413,6 +442,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
             }
         return;
     }
+    float pb[NF][4];
+    preload_cols<NF>(g, n0 + wn0 + fg * 4, pb);
     if (g.act == ACT_GEGLU) {
 #pragma unroll
         for (int i = 0; i < NF; i += 2)
@@ -423,7 +454,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
                 if (m < g.M && n < g.N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     float vg[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
-                    epilogue4<T>(g, z, m, n, v, vg);
+                    epilogue4<T>(g, z, m, n, v, vg, nullptr, nullptr, false, true, nullptr, 0, 0, 0, pb[i], pb[i + 1 < NF ? i + 1 : i]);
                 }
             }
         return;
@@ -436,7 +467,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, z, m, n, v, nullptr);
+                epilogue4<T>(g, z, m, n, v, nullptr, nullptr, nullptr, false, true, nullptr, 0, 0, 0, pb[i]);
             }
         }
 }
@@ -806,6 +837,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             }
         return;
     }
+    float pb[NF][4];
+    preload_cols<NF>(g, n0 + wn0 + fg * 4, pb);
     if (g.act == ACT_GEGLU) {
         if constexpr (NF % 2 == 0) {
 #pragma unroll
@@ -817,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
                     if (m < g.M && n < g.N) {
                         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                         float vg[4] = {acc[i + 1][j][0], acc[i + 1][j][1], acc[i + 1][j][2], acc[i + 1][j][3]};
-                        epilogue4<T>(g, z, m, n, v, vg);
+                        epilogue4<T>(g, z, m, n, v, vg, nullptr, nullptr, false, true, nullptr, 0, 0, 0, pb[i], pb[i + 1]);
                     }
                 }
         }
@@ -849,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 epilogue4<T>(g, z, m, n, v, nullptr, LORA && !lora_mma ? zlds + (m - m0) * 16 : nullptr,
                              staged || (hstaged && !htr) ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later, true,
-                             hstaged && htr ? otile : nullptr, m - m0, n - n0, BM + 8);
+                             hstaged && htr ? otile : nullptr, m - m0, n - n0, BM + 8, pb[i]);
             }
         }
     if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, z, resid_later);
@@ -1047,6 +1080,8 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
     T* otile = reinterpret_cast<T*>(smem);
     const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && (size_t)BM * OPITCH * 2 <= (size_t)pit * 4096 + 2 * WSTAGE && g.stage_out > 1;
     const bool resid_later = staged && g.resid != nullptr && (g.ldr & 7) == 0 && g.stage_out < 3;
+    float pb[NF][4];
+    preload_cols<NF>(g, n0 + wn0 + fg * 4, pb);
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -1055,7 +1090,8 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
             const int n = n0 + wn0 + i * 16 + fg * 4;
             if (m < g.M && n < g.N) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T>(g, 0, m, n, v, nullptr, nullptr, staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later);
+                epilogue4<T>(g, 0, m, n, v, nullptr, nullptr, staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later, true, nullptr,
+                             0, 0, 0, pb[i]);
             }
         }
     if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, 0, resid_later);
@@ -1169,6 +1205,354 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const GemmArgs g, int row_
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) a_cur[kk] = a_nxt[kk];
         }
+    }
+}
+
+// =================================================================================================
+// Row-panel kernel for the short-K row GEMMs of the transformer blocks ("rp"): K = 32*KS <= 640, M large.
+//
+// The tiled kernels above run these shapes far below BOTH rooflines (K = 320, M = 32,768: 6.7 GFLOP + 42 MB in ~30 us):
+// five to ten K tiles per workgroup, each a full load -> drain -> barrier -> 16..32 MFMA round trip, every workgroup of
+// the grid in lock-step, and the activation tile re-fetched into LDS by every N tile.  Here the roles are split by
+// operand instead:
+//   * a workgroup owns a PANEL of 128 rows (a wave: 32 rows = two 16-row MFMA fragments) and keeps the WHOLE K extent of
+//     its rows in REGISTERS in MFMA operand layout (2 x KS x 4 VGPRs per lane), loaded once, straight from global memory
+//     with buffer loads (out-of-range rows read zeros) - the activations never pass through LDS;
+//   * the weights stream through LDS in chunks of BN = 16*NF output columns x the whole K (<= 40 KB), double buffered,
+//     by LDS-DMA; a chunk is ONE barrier interval of KS*2*NF MFMAs per wave (80 at K = 320), so the per-K-tile
+//     drain/barrier of the tiled kernels disappears and the next chunk's load overlaps a long compute phase;
+//   * two fragments of rows per wave halve the LDS fragment reads per MFMA (the earlier weight-stationary kernel, one
+//     fragment per wave, was LDS-read bound: profiles/r01b_ws_sweep.log);
+//   * optional PROLOGUE on the register-resident rows: LayerNorm (statistics over the row with two cross-lane adds,
+//     affine from global) - the separate LayerNorm launch and its HBM round trip of the row tensor disappear;
+//   * grid = panels x ysplit: the N range is split over `ysplit` workgroups so that ~2 workgroups per CU exist.
+// Epilogues as in gemm_bl_kernel (bias, residual, GEGLU, head-major Q/K/V^T, staged row stores, rank-4 LoRA with the
+// down-projection computed in-kernel from the resident rows and the up-projection as one more MFMA K step).
+// =================================================================================================
+typedef __attribute__((ext_vector_type(4))) unsigned rp_u4;
+__device__ __forceinline__ bf16x8 rp_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int KS, int NF, bool LORA, int PRO>
+__global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
+    typedef bf16 T;
+    constexpr int K = KS * 32, BN = NF * 16, BM = 128, MF = 2;
+    constexpr int CPR = KS * 4;                 // 16-byte chunks per weight row
+    constexpr int CHUNK = BN * K * 2;           // bytes of one weight chunk in LDS
+    constexpr int PIECES = BN * CPR / 64;       // 1-KiB LDS-DMA pieces per chunk
+    constexpr int PPW = (PIECES + 3) / 4;       // pieces per wave
+    static_assert((BN * CPR) % 64 == 0, "whole DMA pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int nchunks = (g.N + BN - 1) / BN;
+    const int per = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c_beg = blockIdx.y * per, c_end = min(nchunks, c_beg + per);
+    if (c_beg >= c_end) return;
+
+    const T* ap = reinterpret_cast<const T*>(g.a0);
+    const T* wp = reinterpret_cast<const T*>(g.w);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(ap, (unsigned)min((long long)g.M * g.lda0 * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)min((long long)g.N * K * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(LORA ? g.lora_a : (const void*)wp, LORA ? (unsigned)((long long)g.lora_R * K * 2) : 0u);
+
+    // ---- weight chunk DMA geometry: LDS position L (16-byte units) = row * CPR + (c ^ (row & 7)) ----
+    static_assert(PIECES % 4 == 0, "every wave issues the same number of DMA pieces (no control flow around them: the compiler's\n"
+                                   "wait-count model turns conditional VMEM issue into vmcnt(0) drains)");
+    unsigned wvo[PPW];
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+        const int L = (p * 4 + wave) * 64 + lane;
+        const int row = L / CPR, cs = L - row * CPR;
+        const int c = cs ^ (row & 7);
+        wvo[p] = (unsigned)((row * K + c * 8) * 2);
+    }
+    // `live` false: the chunk does not exist - every lane's offset lies beyond num_records, the DMA writes zeros (harmless)
+    auto stage_w = [&](int chunk, int buf, bool live) {
+        char* sb = smem + buf * CHUNK;
+        const unsigned base = live ? (unsigned)chunk * (unsigned)(BN * K * 2) : 0xC0000000u;  // rows past N also lie beyond num_records
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) bl16(rw, sb + (p * 4 + wave) * 1024, wvo[p], base);
+    };
+
+    // ---- the panel rows: registers, MFMA second-operand layout (row = fr of fragment j, k = 32 kk + 8 fg ..) ----
+    bf16x8 af[MF][KS];
+    {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wave * 32 + j * 16 + fr;
+            const unsigned vo = m < g.M ? (unsigned)(((size_t)m * g.lda0 + fg * 8) * 2) : BL_OOB;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) af[j][kk] = rp_load16(ra, vo, (unsigned)(kk * 64));
+        }
+    }
+    stage_w(c_beg, 0, true);
+    if (LORA) {  // the adapters' A rows (R <= 16) borrow the front of buffer 1 until chunk c_beg + 1 is staged
+        constexpr int LPIECES = 16 * CPR / 64;
+#pragma unroll
+        for (int p = 0; p < (LPIECES + 3) / 4; ++p) {
+            const int piece = p * 4 + wave;
+            const int L = piece * 64 + lane;
+            const int row = L / CPR, cs = L - row * CPR;
+            const int c = cs ^ (row & 7);
+            const unsigned vo = (piece < LPIECES && row < g.lora_R) ? (unsigned)((row * K + c * 8) * 2) : BL_OOB;
+            if (piece < LPIECES) bl16(rl, smem + CHUNK + piece * 1024, vo, 0u);
+        }
+    }
+
+    if (PRO == 1) {
+        // LayerNorm over the K extent of each resident row: a row's K values live in the 4 lanes {fr + 16 fg'}.  ONE statistics pass
+        // with sums shifted by the row's first element c (sum d, sum d^2 with d = x - c: no cancellation for rows with a large common
+        // offset; the inputs carry 8 significant bits), then one apply pass.  `opaque` keeps the compiler from carrying the 160
+        // unpacked f32 values of the first pass over to the second (it spilled hundreds of registers doing so).
+        float mean[MF], rstd[MF];
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const float c0 = __shfl((float)af[j][0][0], fr);  // lane fr (fg = 0) holds the row's element 0
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)af[j][kk][e] - c0; s1 += d; s2 = fmaf(d, d, s2); }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const float md = s1 * (1.0f / K);
+            mean[j] = c0 + md;
+            rstd[j] = rsqrtf(fmaxf(s2 * (1.0f / K) - md * md, 0.f) + g.ln_eps);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                rp_u4 w = __builtin_bit_cast(rp_u4, af[j][kk]);
+                asm volatile("" : "+v"(w));
+                af[j][kk] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        const float* gp = g.ln_gamma + fg * 8;
+        const float* bp = g.ln_beta + fg * 8;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {  // k outer: this k-step's gamma / beta serve both row fragments
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + kk * 32), g1 = *reinterpret_cast<const f32x4*>(gp + kk * 32 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + kk * 32), b1 = *reinterpret_cast<const f32x4*>(bp + kk * 32 + 4);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+                    o[e] = (bf16)(((float)af[j][kk][e] - mean[j]) * rstd[j] * ga + be);
+                }
+                af[j][kk] = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- LoRA: z = x A^T from the resident rows (one 16-column "chunk"), kept in registers as the row operand of the
+    // up-projection step: lane (fr, fg) holds z[m = fr][q = 4 fg + r], which it uses as k elements 0..3 of its k group
+    bf16x8 zf[MF];
+    if (LORA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* sl = smem + CHUNK;
+        f32x4 zacc[MF];
+#pragma unroll
+        for (int j = 0; j < MF; ++j) zacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const bf16x8 lf = *reinterpret_cast<const bf16x8*>(sl + fr * (K * 2) + (((kk * 4 + fg) ^ (fr & 7)) * 16));
+#pragma unroll
+            for (int j = 0; j < MF; ++j) zacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[j][kk], zacc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            zf[j] = bf16x8{(bf16)zacc[j][0], (bf16)zacc[j][1], (bf16)zacc[j][2], (bf16)zacc[j][3], (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            const int m = m0 + wave * 32 + j * 16 + fr;
+            if (g.lora_zout && blockIdx.y == 0 && m < g.M && fg * 4 < g.lora_R)
+                *reinterpret_cast<f32x4*>(g.lora_zout + (size_t)m * g.lora_R + fg * 4) = zacc[j];
+        }
+        __syncthreads();  // every wave is done with the adapter rows: buffer 1 may receive a weight chunk
+    }
+
+    // Outputs (rp_ok admits only these forms): rows [M][ldo] (+ residual rows), GEGLU rows, or head-major Q / K / V^T sections.
+    // Every form leaves through a wave-private staging tile as 16-byte pieces.  The epilogue runs once per CHUNK (up to 20
+    // times per workgroup), so it is straight-line code: the bias is the accumulators' initial value, the operand-mode
+    // branching is per chunk, never per fragment (the generic epilogue4 - ~30 uniform branches and a global-load round trip
+    // per fragment - made the first version of this kernel spend 2/3 of its time between K loops: tools/probes/).
+    const bool has_resid = g.resid != nullptr;
+    constexpr int OPITCH = BN + 8;      // wave-private row tile [32][OPITCH]
+    constexpr int TPITCH = 32 + 8;      // wave-private transposed tile [BN][TPITCH] (V^T)
+    constexpr int GP = BN / 2 + 8;      // GEGLU tile [32][GP]
+    constexpr int WREG = 8192;          // bytes of a wave's staging region inside the chunk's own (consumed) weight buffer
+    static_assert(32 * OPITCH * 2 <= WREG && BN * TPITCH * 2 <= WREG && 4 * WREG <= CHUNK, "staging regions");
+    const int wm0 = wave * 32;
+    const bool full_m = m0 + BM <= g.M;
+    const bool heads = g.out_mode == OUT_HEADS;
+    const bool geglu = g.act == ACT_GEGLU;
+    // stores of the previous chunk's epilogue that may still be in flight at the top of the loop (per lane; -1 = unknown).  The
+    // wait at the top must cover chunk c's LDS-DMA (older than those stores: vmcnt retires in order) but NOT the stores:
+    // waiting for them would serialise every chunk on an HBM write round trip.
+    int pending = 0;
+
+    for (int c = c_beg; c < c_end; ++c) {
+        const int buf = (c - c_beg) & 1;
+        const int n0 = c * BN;
+        // the chunk's bias (GEGLU: interleaved like the weight rows) = initial value of the accumulators; loaded first so that
+        // the wait + barrier below cover its latency.  Columns past N (partial last chunk) are clamped: never stored.
+        float pb[NF][4];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) load4<float>(g.bias + min(n0 + i * 16 + fg * 4, g.N - 4), pb[i]);  // (launch_rp: never null)
+        // counted wait only when every DMA instruction of chunk c is in range (a fully out-of-range LDS-DMA instruction retires
+        // out of order and would satisfy the count early) and the store count is known; the NF bias loads above are younger
+        const int young = pending > 0 && n0 + BN <= g.N ? pending + NF : 0;
+        if (young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (young == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk c has landed; every wave has left chunk c - 1 (its buffer, incl. the staging regions, is free)
+        stage_w(c + 1, buf ^ 1, c + 1 < c_end);  // unconditional issue (see stage_w): the K loop's bias wait stays a counted one
+        bf16x8 lbf[NF];
+        if (LORA) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                lbf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                const int n = n0 + i * 16 + fr;
+                if (n < g.N && n / g.lora_secN == fg) {
+                    const f32x4 l = *reinterpret_cast<const f32x4*>(g.lora_b + (size_t)n * 4);
+                    lbf[i][0] = (bf16)l[0]; lbf[i][1] = (bf16)l[1]; lbf[i][2] = (bf16)l[2]; lbf[i][3] = (bf16)l[3];
+                }
+            }
+        }
+        f32x4 acc[NF][MF];
+        const char* sw = smem + buf * CHUNK + fr * (K * 2);
+        // weight fragments software-pipelined one k-step ahead; the scheduling barriers keep the compiler from hoisting all
+        // KS*NF LDS reads above the MFMAs (it would need the whole register file)
+        bf16x8 wf[2][NF];
+        auto load_w = [&](bf16x8 (&dst)[NF], int kk) {
+            const int phys = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(sw + i * 16 * (K * 2) + phys);
+        };
+        load_w(wf[0], 0);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc[i][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], af[j][kk], cz, 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g.dbg & 128) {  // probe: no epilogue / stores
+            if (acc[0][0][0] == 1.2345e30f) reinterpret_cast<float*>(g.out)[0] = acc[1][1][1] + acc[NF - 1][0][2];
+            pending = 0;
+            continue;
+        }
+        if (LORA) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbf[i], zf[j], acc[i][j], 0, 0, 0);
+        }
+        // ---- epilogue of the chunk ----
+        const bool full = full_m && n0 + BN <= g.N;
+        T* wt = reinterpret_cast<T*>(smem + buf * CHUNK + wave * WREG);
+        __syncthreads();  // every wave has finished reading this chunk's weights: its buffer becomes the staging area
+        if (geglu) {
+            if constexpr (NF % 2 == 0) {
+                // u * gelu(gate) of the chunk's (u, gate) fragment pairs -> [32][BN/2] tile -> 16-byte pieces of the compacted rows
+#pragma unroll
+                for (int i = 0; i < NF; i += 2)
+#pragma unroll
+                    for (int j = 0; j < MF; ++j) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[i][j][r] * gelu_erf_t<T>(acc[i + 1][j][r]));
+                        *reinterpret_cast<bf16x4*>(wt + (j * 16 + fr) * GP + (i >> 1) * 16 + fg * 4) = o;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes (a wave's LDS accesses execute in order)
+                constexpr int CPRG = BN / 16;
+                T* ob = reinterpret_cast<T*>(g.out);
+#pragma unroll
+                for (int it = 0; it < NF / 2; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int row = idx / CPRG, ch = idx - row * CPRG;
+                    const int m = m0 + wm0 + row;
+                    if (m >= g.M || n0 + ch * 16 >= g.N) continue;
+                    *reinterpret_cast<bf16x8*>(ob + (size_t)m * g.ldo + (n0 >> 1) + ch * 8) = *reinterpret_cast<const bf16x8*>(wt + row * GP + ch * 8);
+                }
+                pending = full ? NF / 2 : -1;
+            }
+            continue;
+        }
+        bool htr = false;
+        int sidx = 0;
+        if (heads) {
+            sidx = n0 / g.secC;
+            htr = (sidx == 0 ? g.sec_tr[0] : (sidx == 1 ? g.sec_tr[1] : g.sec_tr[2])) != 0;
+        }
+        T* base = heads ? reinterpret_cast<T*>(sidx == 0 ? g.sec_ptr[0] : (sidx == 1 ? g.sec_ptr[1] : g.sec_ptr[2])) : reinterpret_cast<T*>(g.out);
+        if (!htr) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const bf16x4 o = {(bf16)acc[i][j][0], (bf16)acc[i][j][1], (bf16)acc[i][j][2], (bf16)acc[i][j][3]};
+                    *reinterpret_cast<bf16x4*>(wt + (j * 16 + fr) * OPITCH + i * 16 + fg * 4) = o;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int CPRW = BN / 8;  // 16-byte pieces per row
+#pragma unroll
+            for (int it = 0; it < NF; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / CPRW, ch = idx - row * CPRW;
+                const int m = m0 + wm0 + row, n = n0 + ch * 8;
+                if (m >= g.M || n >= g.N) continue;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(wt + row * OPITCH + ch * 8);
+                if (g.dbg & 512) { if (v[0] == (bf16)1.2345e30f) *reinterpret_cast<bf16x8*>(base) = v; continue; }  // probe: no global store
+                if (!heads) {
+                    if (has_resid) {  // residual read as whole rows too (may alias the output: same lane reads then writes)
+                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(g.resid) + (size_t)m * g.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(base + (size_t)m * g.ldo + n) = v;
+                } else {
+                    const int cc = n - sidx * g.secC, h = cc / g.hd, dd = cc - h * g.hd;
+                    const int b = m / g.ntok, tok = m - b * g.ntok;
+                    *reinterpret_cast<bf16x8*>(base + (((size_t)b * g.nheads + h) * g.npad + tok) * g.dpad + dd) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    unsigned w0, w1;
+                    const int drow = exchange_tokens4(v, w0, w1);
+                    *reinterpret_cast<uint2*>(wt + (i * 16 + fg * 4 + drow) * TPITCH + ((j * 16 + fr) & ~3)) = make_uint2(w0, w1);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < NF; ++it) {
+                const int idx = it * 64 + lane;
+                const int col = idx >> 2, tc = idx & 3;  // 4 pieces of 8 tokens per channel row
+                const int m = m0 + wm0 + tc * 8, n = n0 + col;
+                if (m >= g.M || n >= g.N) continue;
+                const int cc = n - sidx * g.secC, h = cc / g.hd, dd = cc - h * g.hd;
+                const int b = m / g.ntok, tok = m - b * g.ntok;
+                *reinterpret_cast<bf16x8*>(base + (((size_t)b * g.nheads + h) * g.dpad + dd) * g.npad + tok) =
+                    *reinterpret_cast<const bf16x8*>(wt + col * TPITCH + tc * 8);
+            }
+        }
+        pending = full ? NF : -1;
     }
 }
 
@@ -1439,6 +1823,98 @@ static int launch_ws(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// row-panel configurations: id -> <KS, NF>   (K = 32*KS, weight chunks of 16*NF output columns x K = 40 KB)
+#define RP_CFGS(X)   \
+    X(60, 10, 4)     \
+    X(61, 20, 2)
+
+static void rp_dims(int tile, int* ks, int* nf) {
+    *ks = *nf = 0;
+    switch (tile) {
+#define X(id, k, n) case id: *ks = k; *nf = n; break;
+        RP_CFGS(X)
+#undef X
+    }
+}
+static bool rp_ok(const GemmArgs& g, int tile) {
+    int ks, nf;
+    rp_dims(tile, &ks, &nf);
+    const int bn = nf * 16;
+    if (!ks || g.no_rp || g.conv || g.c1 || g.a1 || g.batch != 1 || g.heads != 1 || g.splitk > 1) return false;
+    if (g.K != 32 * ks || g.lda0 % 8 != 0 || g.N % 16 != 0 || g.M < 1) return false;
+    if (g.alpha != 1.0f || g.rowvec || g.lora_z || (!g.bias && (size_t)g.N * sizeof(float) > kZeroPageBytes)) return false;
+    if (g.act == ACT_GEGLU) {
+        if (g.N % 32 != 0 || (nf & 1) || g.out_mode != OUT_ROWS || g.ldo % 8 != 0 || g.resid) return false;
+    } else if (g.act != ACT_NONE) {
+        return false;
+    } else if (g.out_mode == OUT_ROWS) {
+        if (g.ldo % 8 != 0 || (g.resid && g.ldr % 8 != 0)) return false;
+    } else if (g.out_mode == OUT_HEADS) {
+        // head-major sections: every chunk inside one section, everything 8-aligned (16-byte pieces), no residual
+        if (g.secC <= 0 || g.secC % bn != 0 || ((g.N | g.M | g.hd | g.secC | g.dpad | g.npad | g.ntok) & 7) != 0 || g.resid) return false;
+    } else {
+        return false;
+    }
+    if (g.lora_a && (g.lora_r != 4 || g.lora_R > 16 || !g.lora_b || g.act == ACT_GEGLU)) return false;
+    return (long long)g.M * g.lda0 * 2 < 0x7FFFFFFFll && (long long)g.N * g.K * 2 < 0x7FFFFFFFll;
+}
+// the row-panel configuration for this K (0: none)
+int gemm_rp_tile(const GemmArgs& g) {
+    static const int env = [] { const char* e = getenv("MRISR_RP"); return e ? atoi(e) : 1; }();
+    if (!env) return 0;
+#define X(id, k, n) if (g.K == 32 * k && rp_ok(g, id)) return id;
+    RP_CFGS(X)
+#undef X
+    return 0;
+}
+template <int KS, int NF>
+static int launch_rp(const GemmArgs& g, hipStream_t st) {
+    constexpr int K = KS * 32, BN = NF * 16;
+    constexpr int smem = 2 * BN * K * 2;
+    MRISR_REQUIRE(rp_ok(g, KS == 10 ? 60 : 61), "row-panel kernel: plain un-split bf16 row GEMM with K = 32*KS");
+    static bool attr = false;
+    if (!attr) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    const int panels = (g.M + 127) / 128, nchunks = (g.N + BN - 1) / BN;
+    static const int ys_env = [] { const char* e = getenv("MRISR_RP_YSPLIT"); return e ? atoi(e) : 0; }();
+    int ysplit = ys_env > 0 ? ys_env : (512 + panels / 2) / panels;  // ~2 workgroups per CU
+    ysplit = std::max(1, std::min(ysplit, nchunks));
+    static const std::string base_name = std::string("gemm_bf16_rp") + std::to_string(K) + "x" + std::to_string(BN);
+    std::string pname = base_name;
+    if (prof_enabled() && prof_shapes()) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s lin%s M=%d N=%d K=%d s=1 b=1", base_name.c_str(), g.ln_gamma ? "+ln" : "", g.M, g.N, g.K);
+        pname = buf;
+    }
+    double fl = g.alg_flops, by = g.alg_bytes;
+    if (prof_enabled()) {
+        if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K;
+        if (by == 0.0) by = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+    }
+    ProfScope ps(prof_intern(pname), fl, by, st);
+    const dim3 grid(panels, ysplit);
+    const bool lora = g.lora_a != nullptr;
+    if (!g.bias) {  // the kernel loads its chunk's bias unconditionally (straight-line code around the wait counts): zeros
+        MRISR_REQUIRE((size_t)g.N * sizeof(float) <= kZeroPageBytes, "row-panel kernel without bias: N beyond the zero page");
+        const_cast<GemmArgs&>(g).bias = static_cast<const float*>(zero_page());
+    }
+    if (g.ln_gamma) {
+        MRISR_REQUIRE(g.ln_beta, "LayerNorm prologue: gamma and beta");
+        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 1>), grid, dim3(256), smem, st, g);
+        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 1>), grid, dim3(256), smem, st, g);
+    } else {
+        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 0>), grid, dim3(256), smem, st, g);
+        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 0>), grid, dim3(256), smem, st, g);
+    }
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // buffer descriptors address at most 2^31 bytes per operand
 static bool bl_ok(const GemmArgs& g) {
     const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
@@ -1585,7 +2061,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
     // 50-52 (weight-stationary short-K kernels) are NOT candidates: correct, but 30-60 % slower than the tiled kernels on
     // every shape they fit (profiles/r01b_ws_sweep.log: one A fragment per wave makes them LDS-read bound); kept for the record
-    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
+    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45, 60, 61};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
         {   // debugging aid: MRISR_TUNE_SKIP="41,43" removes candidates
@@ -1593,7 +2069,8 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
             if (!skip.empty() && ("," + skip + ",").find("," + std::to_string(tile) + ",") != std::string::npos) continue;
         }
         if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
-        if (tile >= 50 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
+        if (tile >= 50 && tile < 60 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
+        if (tile >= 60 && !rp_ok(g, tile)) continue;  // row-panel kernels: K = 320 / 640 row GEMMs
         // 5 fragments per wave along N (BN = 160): no (u, gate) pairing for the GEGLU epilogue
         if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
@@ -1656,9 +2133,15 @@ extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
 
 int gemm_choose(GemmArgs& g, bool is_bf16) {
     int t = 0, s = 1;
+    if (g.ln_gamma) {  // a fused LayerNorm prologue exists only in the row-panel kernel (the caller checked gemm_rp_tile)
+        g.tile = gemm_rp_tile(g);
+        g.splitk = 1;
+        MRISR_REQUIRE(g.tile != 0, "LayerNorm prologue needs the row-panel kernel");
+        return 0;
+    }
     if (g_force_tile) { g.tile = g_force_tile; if (g.splitk < 1) g.splitk = 1; return 0; }
     if (g_prefer_tile && is_bf16 && bl_ok(g) &&
-        ((g_prefer_tile >= 50 && ws_ok(g, g_prefer_tile)) || (g_prefer_tile >= 40 && g_prefer_tile < 50 && halo_ok(g, halo_bm(g_prefer_tile))))) {
+        ((g_prefer_tile >= 60 && rp_ok(g, g_prefer_tile)) || (g_prefer_tile >= 50 && g_prefer_tile < 60 && ws_ok(g, g_prefer_tile)) || (g_prefer_tile >= 40 && g_prefer_tile < 50 && halo_ok(g, halo_bm(g_prefer_tile))))) {
         g.tile = g_prefer_tile;
         g.splitk = 1;
         return 0;
@@ -1670,6 +2153,7 @@ int gemm_choose(GemmArgs& g, bool is_bf16) {
         plan(g, is_bf16, 0, &t, &s);
     }
     (void)cs;
+    if (t >= 60 && !rp_ok(g, t)) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
     if (g_force_split > 1 && g.act != ACT_GEGLU && g.K / (is_bf16 ? 64 : 32) >= g_force_split && !g.lora_a) {
         s = g_force_split;
         if (t >= 50) t = is_bf16 ? 14 : 1;
@@ -1717,6 +2201,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 #undef X
 #define X(id, ks, nb) case id: rc = launch_ws<ks, nb>(g, st); break;
         WS_CFGS(X)
+#undef X
+#define X(id, ks, nf) case id: rc = launch_rp<ks, nf>(g, st); break;
+        RP_CFGS(X)
 #undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
     }

@@ -18,6 +18,12 @@ namespace mrisr {
 #endif
 
 // MRISR_LORA_INKERNEL=0 restores the separate down-projection pass (A/B measurements)
+// MRISR_FUSE_LN=0: LayerNorm always as its own launch (A/B measurements)
+inline bool fuse_ln() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MRISR_FUSE_LN"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 inline bool lora_in_kernel() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MRISR_LORA_INKERNEL"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -96,8 +102,11 @@ struct Runner {
     }
 
     // y[M][n] = x[M][k] W^T (+LoRA tail) + bias ...; x given as raw rows
+    //   ln / ln_scratch: y = LayerNorm(x) W^T ...  The normalisation runs as a prologue of the row-panel kernel on its
+    //   register-resident rows when that kernel takes the shape (bf16, K = 320 / 640); otherwise as its own launch into
+    //   ln_scratch ([M][k] of T), which then feeds the GEMM.
     int linear(const void* x, int M, int lda, const LinW& lw, int act, const void* resid, int ldr, GemmArgs* custom,
-               void* out, int ldo, float** z_out = nullptr) {
+               void* out, int ldo, float** z_out = nullptr, const NormW* ln = nullptr, void* ln_scratch = nullptr) {
         GemmArgs g = custom ? *custom : GemmArgs();
         const size_t mk = m.arena.mark();
         g.a0 = x; g.c0 = lw.k; g.lda0 = lda;
@@ -105,6 +114,20 @@ struct Runner {
         g.alg_flops = 2.0 * M * (double)lw.n * (lw.k + lw.r);
         g.bias = lw.b; g.act = act; g.resid = resid; g.ldr = ldr;
         if (g.out_mode != OUT_HEADS) { g.out = out; g.ldo = ldo; }
+        // the row-panel kernel fuses LoRA only in the in-kernel rank-4 form
+        if (lw.R && !(lw.r == 4 && lw.R <= 16 && lora_in_kernel())) g.no_rp = 1;
+        if (ln) {
+            MRISR_REQUIRE(ln->c == lw.k && lda == lw.k, "LayerNorm width vs the projection's K");
+            GemmArgs probe = g;  // eligibility as the launch will see it (the in-kernel LoRA form, rank 4, is part of it)
+            if (lw.R) { probe.lora_a = lw.loraA; probe.lora_b = lw.loraB; probe.lora_r = lw.r; probe.lora_R = lw.R; }
+            if (sizeof(T) == 2 && !m.keep && fuse_ln() && (!lw.R || (lw.R <= 16 && lora_in_kernel())) && gemm_rp_tile(probe)) {
+                g.ln_gamma = ln->g; g.ln_beta = ln->b; g.ln_eps = 1e-5f;
+            } else {
+                MRISR_REQUIRE(ln_scratch, "LayerNorm scratch rows");
+                TRY(layernorm(x, *ln, M, lw.k, ln_scratch));
+                g.a0 = x = ln_scratch;
+            }
+        }
         if (!lw.R) {
             TRY(run_gemm(g));
             if (!m.keep) m.arena.release(mk);
@@ -118,7 +141,8 @@ struct Runner {
         float* z = static_cast<float*>(alloc((size_t)M * lw.R * sizeof(float)));
         if (!z) return 7;
         if (z_out) *z_out = z;
-        const bool in_kernel = sizeof(T) == 2 && lw.R <= 16 && g.splitk == 1 && g.tile >= 14 && lora_in_kernel();
+        const bool in_kernel = sizeof(T) == 2 && lw.R <= 16 && g.splitk == 1 && g.tile >= 14 && lora_in_kernel() && (g.tile < 60 || lw.r == 4);
+        MRISR_REQUIRE(in_kernel || !g.ln_gamma, "fused LayerNorm needs the in-kernel LoRA form");
         if (in_kernel) {
             g.lora_a = lw.loraA; g.lora_R = lw.R; g.lora_zout = z_out ? z : nullptr;
         } else {
@@ -245,29 +269,26 @@ struct Runner {
         if (!t || !nrm || !ao) return 7;
         TRY(linear(xn.p, M, C, xw.proj_in, ACT_NONE, nullptr, 0, nullptr, t, C));
         // self-attention
-        TRY(layernorm(t, xw.ln1, M, C, nrm));
         {
             GemmArgs g;
             heads_args(&g, hb, hb.q, 0, hb.k, 0, hb.vt, 1, hb.N, hb.npad);
-            TRY(linear(nrm, M, C, xw.qkv, ACT_NONE, nullptr, 0, &g, nullptr, 0));
+            TRY(linear(t, M, C, xw.qkv, ACT_NONE, nullptr, 0, &g, nullptr, 0, nullptr, &xw.ln1, nrm));
         }
         TRY(attention(hb, hb.k, hb.vt, hb.N, hb.npad, ao));
         TRY(linear(ao, M, C, xw.out1, ACT_NONE, t, C, nullptr, t, C));
         // cross-attention (K/V cached by set_context)
-        TRY(layernorm(t, xw.ln2, M, C, nrm));
         {
             GemmArgs g;
             heads_args(&g, hb, hb.q, 0, nullptr, 0, nullptr, 0, hb.N, hb.npad);
-            TRY(linear(nrm, M, C, xw.q2, ACT_NONE, nullptr, 0, &g, nullptr, 0));
+            TRY(linear(t, M, C, xw.q2, ACT_NONE, nullptr, 0, &g, nullptr, 0, nullptr, &xw.ln2, nrm));
         }
         TRY(attention(hb, xw.kc, xw.vtc, m.ctx_len, m.ctx_pad, ao));
         TRY(linear(ao, M, C, xw.out2, ACT_NONE, t, C, nullptr, t, C));
         // GEGLU feed-forward
-        TRY(layernorm(t, xw.ln3, M, C, nrm));
         {
             T* ff = static_cast<T*>(alloc((size_t)M * 4 * C * sizeof(T)));
             if (!ff) return 7;
-            TRY(linear(nrm, M, C, xw.ff1, ACT_GEGLU, nullptr, 0, nullptr, ff, 4 * C));
+            TRY(linear(t, M, C, xw.ff1, ACT_GEGLU, nullptr, 0, nullptr, ff, 4 * C, nullptr, &xw.ln3, nrm));
             TRY(linear(ff, M, 4 * C, xw.ff2, ACT_NONE, t, C, nullptr, t, C));
         }
         TRY(linear(t, M, C, xw.proj_out, ACT_NONE, x.p, C, nullptr, o.p, C));

@@ -54,6 +54,20 @@ def linear(x, weight, bias=None, act=L.ACT_NONE, splitk=0, tile=0):
     return y
 
 
+def ln_linear(x, gamma, beta, weight, bias=None, act=L.ACT_NONE):
+    """LayerNorm(x) W^T + bias, the normalisation fused into the row-panel GEMM (bf16, K = 320 / 640)."""
+    x = x.contiguous()
+    w = weight.detach().to(torch.float32).contiguous()
+    b = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+    ga, be = (t.detach().to(torch.float32).contiguous() for t in (gamma, beta))
+    n = w.shape[0]
+    y = torch.empty((x.shape[0], n // 2 if act == L.ACT_GEGLU else n), dtype=x.dtype, device=x.device)
+    tx, ty = L.as_tensor(x), L.as_tensor(y)
+    L.check(L.lib().mrisr_op_ln_linear(C.byref(tx), C.c_void_p(ga.data_ptr()), C.c_void_p(be.data_ptr()), C.c_void_p(w.data_ptr()),
+                                       C.c_void_p(b.data_ptr()) if b is not None else None, n, act, C.byref(ty), L.stream_ptr()))
+    return y
+
+
 def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None):
     xb, tx = _nhwc(x)
     t2 = None

@@ -392,4 +392,6 @@ def test_ema_and_checkpoint_roundtrip(tiny, tmp_path):
         save_file(bad, str(tmp_path / "bad.safetensors"))
         fresh().load_checkpoint(str(tmp_path / "bad.safetensors"))
     tr.save_checkpoint(str(tmp_path / "ema.safetensors"), use_ema=True)
-    assert rel(torch.cat([load_file(str(tmp_path / "ema.safetensors"))[k].reshape(-1) for k, _, _ in tr.layout]), tr.ema) < 1e-7
+    from mrisr.train import lora_keys_from_disk
+    ema_sd = lora_keys_from_disk(load_file(str(tmp_path / "ema.safetensors")))
+    assert rel(torch.cat([ema_sd[k].reshape(-1) for k, _, _ in tr.layout]), tr.ema) < 1e-7

@@ -24,7 +24,7 @@ unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_a
 unet.load_state_dict(sd)
 sched = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
 sched.set_timesteps(50)
-lr_lat, ctx, noise = bench.synthetic_batch(32, dev, 0)
+lr_lat, ctx, noise, _hr = bench.synthetic_batch(32, dev, 0)
 lat = (lr_lat + noise).contiguous()
 smp = mrisr.Sampler(unet, sched, kind="ddim")
 smp.set_range(0, 1)

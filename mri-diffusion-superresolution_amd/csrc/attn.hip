@@ -26,7 +26,20 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
 
-template <int DPAD, int DB, int QF>
+// (cross-row-group reductions stay on ds_bpermute: the gfx950 v_permlane16/32_swap builtins were tried - both results of the
+// builtin come back as {row 0, row 0, row 2, row 2}, i.e. only the odd rows receive their partner, tools/probes/permlane_test.hip -
+// so one swap does not give the symmetric exchange a reduction needs)
+// The key loop of this kernel is VALU-issue bound (one exp per 160 FLOP at hd = 40), so everything that is not an exp, a
+// max or a pack has been moved onto the matrix cores or out of the loop:
+//   * Q is pre-scaled by scale * log2(e) once per wave (f32, rounded back to bf16), so S comes out in log2 units;
+//   * the running reference -m is the C INPUT of the first S MFMA: the product leaves the matrix core as s - m, ready for
+//     v_exp_f32 - no per-score FMA;
+//   * the row sum l is one more row of the P.V product: ONES = the 16-row block holding row `hd` of V^T has spare rows (hd = 40:
+//     rows 40..47 of the third block), the tile commit writes 1.0 into row hd, and O^T[hd] accumulates sum_k p - no per-score add;
+//   * the reference m moves only when a tile's maximum exceeds it by more than THR (2^8) - or on the first tile - so the
+//     accumulator rescale is a rarely taken wave-uniform branch (exact: everything at the old reference is rescaled once,
+//     nothing else; p <= 2^8 keeps bf16 P relative precision and f32 sums far from overflow);
+template <int DPAD, int DB, int QF, bool ONES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int KT = 64;                  // keys per LDS tile
     constexpr int KSTEPS = DPAD / 32;       // MFMA k-steps over the head dim for S
@@ -34,8 +47,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int KP = DPAD * 2 + 16;       // K tile row pitch (bytes), padded
     constexpr int VP = KT * 2 + 16;         // V^T tile row pitch (bytes), padded
     constexpr int CPT = DPAD / 32;          // 16-byte chunks per thread per tile (K and V^T alike)
-    __shared__ __attribute__((aligned(16))) char k_lds[KT * KP];
-    __shared__ __attribute__((aligned(16))) char v_lds[DPAD * VP];
+    constexpr float THR = 8.0f;
+    // two tile buffers: tile t + 1 is committed while tile t is consumed - ONE barrier per tile
+    __shared__ __attribute__((aligned(16))) char k_lds2[2][KT * KP];
+    __shared__ __attribute__((aligned(16))) char v_lds2[2][DPAD * VP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -55,20 +70,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const bf16* vb = reinterpret_cast<const bf16*>(a.vt) + (size_t)bh * DPAD * a.nkpad;
     const float sl2 = a.scale * 1.4426950408889634f;
 
-    // Q fragments (second MFMA operand: rows = q, d-contiguous), straight from global
+    // Q fragments (second MFMA operand: rows = q, d-contiguous), straight from global, pre-scaled to log2 units
     bf16x8 qf[QF][KSTEPS];
     const int q_last = (a.nq + 63) / 64 * 64 - 1;  // last row of this head's (padded) q buffer
 #pragma unroll
     for (int f = 0; f < QF; ++f)
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk)
-            qf[f][kk] = *reinterpret_cast<const bf16x8*>(qb + (size_t)min(q0 + f * 16 + fr, q_last) * DPAD + kk * 32 + fg * 8);
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(qb + (size_t)min(q0 + f * 16 + fr, q_last) * DPAD + kk * 32 + fg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[f][kk][e] = (bf16)((float)raw[e] * sl2);
+        }
 
     f32x4 oacc[QF][DB];
     float m_run[QF], l_run[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-        m_run[f] = -INFINITY;
+        m_run[f] = 0.f;
         l_run[f] = 0.f;
 #pragma unroll
         for (int d = 0; d < DB; ++d) oacc[f][d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -84,8 +102,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         kptr[i] = kb + (size_t)(c / (DPAD / 8)) * DPAD + (c % (DPAD / 8)) * 8;   // K tile: KT rows x DPAD/8 chunks
         vptr[i] = vb + (size_t)(c >> 3) * a.nkpad + (c & 7) * 8;                 // V^T tile: DPAD rows x 8 chunks
     }
-    auto fetch = [&](int kt0) {  // called with consecutive tiles: the pointers just advance
-        (void)kt0;
+    auto fetch = [&]() {  // called with consecutive tiles: the pointers just advance
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             kreg[i] = *reinterpret_cast<const bf16x8*>(kptr[i]);
@@ -94,30 +111,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
             vptr[i] += KT;
         }
     };
-    auto commit = [&]() {
+    const bf16 one = (bf16)1.0f;
+    auto commit = [&](int buf) {
+        char* k_l = k_lds2[buf];
+        char* v_l = v_lds2[buf];
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = i * 256 + tid;
             {
                 const int row = c / (DPAD / 8), ch = c % (DPAD / 8);
-                *reinterpret_cast<bf16x8*>(k_lds + row * KP + ch * 16) = kreg[i];
+                *reinterpret_cast<bf16x8*>(k_l + row * KP + ch * 16) = kreg[i];
             }
             {
                 const int row = c >> 3, ch = c & 7;
-                *reinterpret_cast<bf16x8*>(v_lds + row * VP + ch * 16) = vreg[i];
+                bf16x8 v = vreg[i];
+                if (ONES && row == a.hd) v = bf16x8{one, one, one, one, one, one, one, one};  // the row-sum row of V^T
+                *reinterpret_cast<bf16x8*>(v_l + row * VP + ch * 16) = v;
             }
         }
     };
 
     const int ntiles = (a.nk + KT - 1) / KT;
-    fetch(0);
+    fetch();
+    commit(0);
+    if (ntiles > 1) fetch();
     for (int t = 0; t < ntiles; ++t) {
         const int kt0 = t * KT;
-        __syncthreads();  // previous tile fully consumed
-        commit();
-        __syncthreads();
-        if (t + 1 < ntiles) fetch(kt0 + KT);
-        // ---- S^T for 64 keys x (QF*16) queries: 4 key blocks of 16 ----
+        const char* k_lds = k_lds2[t & 1];
+        const char* v_lds = v_lds2[t & 1];
+        __syncthreads();  // tile t is visible; every wave has finished tile t - 1 (whose buffer receives tile t + 1 now)
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch();
+        }
+        // ---- S^T - m for 64 keys x (QF*16) queries: 4 key blocks of 16 ----
         f32x4 s[QF][4];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -126,14 +153,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
 #pragma unroll
                 for (int f = 0; f < QF; ++f) {
-                    // first k-step: C = 0 as an inline constant (no zero-initialised accumulator registers)
-                    const f32x4 c = kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[f][tt];
+                    const float nm = -m_run[f];
+                    const f32x4 c = kk == 0 ? f32x4{nm, nm, nm, nm} : s[f][tt];
                     s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], c, 0, 0, 0);
                 }
             }
         }
         const bool ragged = kt0 + KT > a.nk;  // only the last tile can hold masked keys (uniform branch)
-        // ---- online softmax, once per 64 keys: lane owns q = fr; its 16 values are keys 16tt + 4fg + r ----
         uint4v pw[QF][2];  // P^T fragments as packed bf16 pairs (second MFMA operand)
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
@@ -144,34 +170,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (kt0 + tt * 16 + fg * 4 + r >= a.nk) s[f][tt][r] = -INFINITY;
             }
-            // the softmax is the VALU bound of this kernel (SQ counters: VALU busy 76 % of the SIMD's cycles): keep it
-            // to v_max3 chains and packed-f32 FMAs / adds (two values per instruction)
-            float mx = s[f][0][0];
+            // lane owns q = fr; its 16 values are keys 16tt + 4fg + r, already relative to the running reference
+            float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
+            for (int tt = 1; tt < 4; ++tt) {
                 mx = fmaxf(fmaxf(mx, s[f][tt][0]), s[f][tt][1]);
                 mx = fmaxf(fmaxf(mx, s[f][tt][2]), s[f][tt][3]);
             }
-            mx = xor_max(mx) * sl2;                       // running max kept in the scaled (log2) domain
-            const float m_new = fmaxf(m_run[f], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
-            m_run[f] = m_new;
-            const f32x2 sl2v = {sl2, sl2}, nmv = {-m_new, -m_new};
-            f32x2 ps2 = {0.f, 0.f};
+            // move the reference only when it is needed: first tile (any sign), or some score of the tile is beyond 2^THR - tested
+            // on the lane-LOCAL maxima (no lane above THR <=> no score above THR), so the cross-lane exchange that makes the four
+            // lanes of a query agree on the new reference is paid only inside the rarely taken branch
+            if (t == 0 || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {
+                mx = xor_max(mx);
+                const float dlt = t == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-dlt);  // (tile 0: the accumulators are zero, any factor is fine)
+                m_run[f] += dlt;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[f][tt][r] -= dlt;
+                if (t != 0) {
+                    l_run[f] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
+                }
+            }
+            float ps = 0.f;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
-                    const f32x2 x = {s[f][tt][r], s[f][tt][r + 1]};
-                    const f32x2 e = __builtin_elementwise_fma(x, sl2v, nmv);  // scale*(s - max) in log2 units
-                    const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-                    ps2 += p;
+                    const f32x2 p = {__builtin_amdgcn_exp2f(s[f][tt][r]), __builtin_amdgcn_exp2f(s[f][tt][r + 1])};
+                    if (!ONES) ps += p[0] + p[1];
                     pw[f][tt >> 1][(tt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // one v_cvt_pk
                 }
-            const float ps = ps2[0] + ps2[1];
-            l_run[f] = l_run[f] * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
+            if (!ONES) l_run[f] += ps;
         }
         // ---- O^T += V^T . P^T : two 32-key steps ----
 #pragma unroll
@@ -196,7 +229,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     bf16* ob = reinterpret_cast<bf16*>(a.out);
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-        const float lsum = xor_sum(l_run[f]);
+        float lsum;
+        if (ONES) {
+            // O^T row hd is the row sum: block hd / 16, lane group (hd % 16) / 4, register hd % 4
+            float cand = 0.f;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (d * 16 + fg * 4 + r == a.hd) cand = oacc[f][d][r];
+            lsum = xor_sum(cand);  // the three other lane groups contribute 0
+        } else {
+            lsum = xor_sum(l_run[f]);
+        }
         const float inv = 1.0f / lsum;
         const int q = q0 + f * 16 + fr;
         if (a.lse && fg == 0 && q <= q_last)  // log2-domain log-sum-exp per query; +inf on the padding rows (P = 0 there)
@@ -222,10 +267,14 @@ static int launch_dpad(const AttnArgs& a, hipStream_t st) {
     const_cast<AttnArgs&>(a).xcd_map = (xcd_env && BH % 8 == 0) ? 1 : 0;
     ProfScope ps("flash_attention", 4.0 * BH * (double)a.nq * a.nk * a.hd,
                  2.0 * BH * (2.0 * a.nq * a.hd + 2.0 * a.nk * a.hd), st);
+    // ONES: the row sum rides along the P.V product as row `hd` of V^T - needs a spare row in the last 16-row block
+    const bool ones = a.hd < DB * 16;
     if (a.nq >= 128) {
-        hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 2>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
+        if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 2, true>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 2, false>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 1>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
+        if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 1, true>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 1, false>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
     }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;

@@ -60,6 +60,9 @@ typedef struct {
     int32_t lora_rank;              /* 0 = no LoRA; else rank of the peft adapters that will be set */
     int32_t lora_fused;             /* 1: rank-r tail fused into the projection GEMMs; 0: merged into W at finalize */
     int32_t flash_attention;        /* 1: fused flash kernel (bf16 only); 0: materialised scores */
+    int32_t fp8_linears;            /* 0: off; 1: K = 320 projections; 2: K = 320 and 640 (bf16 models): these projections of the transformer blocks - incl. the LoRA
+                                       targets to_q/k/v, to_out - run with OCP e4m3 operands on the fp8 MFMA (per-output-channel
+                                       weight scales, per-row activation scales computed in-kernel), f32 accumulate; BASELINE configs[4] */
 } mrisr_unet_cfg;
 
 typedef struct mrisr_model mrisr_model; /* UNet2DConditionModel or ControlNetModel */
@@ -271,6 +274,10 @@ int mrisr_op_linear(const mrisr_tensor* x_rows, const float* w_dev, const float*
  * K = 320 or 640, n % 16 == 0) - the form the transformer blocks use for norm1/2/3 -> to_q|k|v / to_q / ff.net.0.proj */
 int mrisr_op_ln_linear(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, const float* w_dev,
                        const float* bias_dev, int n, int act, mrisr_tensor* y_rows, void* stream);
+/* the fp8 form of the same projection (BASELINE configs[4]): weights quantised to OCP e4m3 with one scale per output channel, the
+ * rows with one scale per row inside the kernel, f32 accumulate; gamma_dev / beta_dev NULL = no LayerNorm prologue */
+int mrisr_op_linear_fp8(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, const float* w_dev,
+                        const float* bias_dev, int n, int act, mrisr_tensor* y_rows, void* stream);
 int mrisr_op_groupnorm(const mrisr_tensor* x_nhwc, const mrisr_tensor* x2_nhwc, const float* gamma_dev,
                        const float* beta_dev, int groups, float eps, int silu, mrisr_tensor* y_nhwc, void* stream);
 int mrisr_op_layernorm(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, float eps,

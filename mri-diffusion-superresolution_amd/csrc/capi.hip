@@ -1036,6 +1036,40 @@ int mrisr_op_ln_linear(const mrisr_tensor* x, const float* gamma_dev, const floa
     API_END
 }
 
+int mrisr_op_linear_fp8(const mrisr_tensor* x, const float* gamma_dev, const float* beta_dev, const float* w_dev, const float* bias_dev,
+                        int n, int act, mrisr_tensor* y, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    TRY(gemm_prepare());
+    MRISR_REQUIRE(x->ndim == 2 && y && y->ndim == 2 && y->dtype == x->dtype && x->dtype == MRISR_BF16 && w_dev, "bf16 rows in/out");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)x->shape[0], K = (int)x->shape[1];
+    DevBuf wp, w8, ws, bp;
+    TRY(wp.reserve((size_t)n * K * 2, false));
+    TRY(w8.reserve((size_t)n * K, false));
+    TRY(ws.reserve((size_t)n * sizeof(float), false));
+    const bool geglu = act == ACT_GEGLU;
+    TRY(launch_pack_rows<bf16>(w_dev, n, K, wp.p, K, 0, 0, geglu ? 1 : 0, n / 2, 1.0f, st));
+    TRY(launch_quant_rows_fp8(wp.p, n, K, w8.p, static_cast<float*>(ws.p), st));
+    const float* bias = bias_dev;
+    if (geglu && bias_dev) {
+        TRY(bp.reserve((size_t)n * sizeof(float), false));
+        TRY(launch_pack_bias_geglu(bias_dev, static_cast<float*>(bp.p), n / 2, st));
+        bias = static_cast<const float*>(bp.p);
+    }
+    GemmArgs g;
+    g.a0 = x->data; g.c0 = K; g.lda0 = K; g.w = wp.p; g.M = M; g.N = n; g.K = K; g.bias = bias; g.act = act;
+    g.out = y->data; g.ldo = (int)y->shape[1];
+    g.w8 = w8.p; g.w_scale = static_cast<const float*>(ws.p);
+    MRISR_REQUIRE(gemm_rp_tile(g) != 0, "fp8 operands: the row-panel kernel does not take this shape (K = 320 / 640, N % 16 == 0)");
+    if (gamma_dev) { g.ln_gamma = gamma_dev; g.ln_beta = beta_dev; g.ln_eps = 1e-5f; }
+    TRY(gemm_choose(g, true));
+    TRY(launch_gemm<bf16>(g, st));
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+    API_END
+}
+
 int mrisr_op_groupnorm(const mrisr_tensor* x, const mrisr_tensor* x2, const float* gamma_dev, const float* beta_dev,
                        int groups, float eps, int silu, mrisr_tensor* y, void* stream) {
     API_BEGIN

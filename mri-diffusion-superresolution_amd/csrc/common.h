@@ -133,6 +133,12 @@ struct GemmArgs {
     const float* ln_gamma = nullptr;
     const float* ln_beta = nullptr;
     float ln_eps = 1e-5f;
+    // fp8 (OCP e4m3) operands of the row-panel kernel: weights [N][K] bytes + one f32 scale per output channel; LoRA A rows
+    // [lora_R][K] bytes + one scale per adapter row (packed at finalize when the model's fp8 flag is set)
+    const void* w8 = nullptr;
+    const float* w_scale = nullptr;
+    const void* lora_a8 = nullptr;
+    const float* lora_a_scale = nullptr;
     int no_rp = 0;    // the caller's operand forms rule the row-panel kernel out (e.g. LoRA of a rank it does not fuse)
     int group_m = 1;  // M tiles per group of the tile order (set by the launchers: auto_group_m; MRISR_GROUP_M)
     int dbg = 0;  // cross-check switches (mrisr_debug_gemm_flags): 8 scalar LoRA up-projection, 16 unstaged head-major stores
@@ -315,6 +321,8 @@ template <typename T>
 int launch_pack_conv3x3_padded(const float* src, void* dst, int Cout, int Cin, int ks, int Cout_pad, int Cin_pad, hipStream_t st);
 int launch_pack_bias_geglu(const float* src, float* dst, int half, hipStream_t st);
 template <typename T> int launch_fill_zero(void* p, long long n, hipStream_t st);
+// packed bf16 rows -> OCP e4m3 rows + one f32 scale per row (amax / 448)
+int launch_quant_rows_fp8(const void* src_bf16, int rows, int cols, void* dst8, float* scales, hipStream_t st);
 // sampler steps (f32 state, NCHW like the reference's latents)
 //   ddim: x = cx*x + ce*eps;   coefficients read from a device table indexed by *step_idx
 int launch_ddim_step(float* x, const float* eps, const float* coef_table, const int* step_idx, long long n,

@@ -1234,12 +1234,31 @@ __device__ __forceinline__ bf16x8 rp_load16(__amdgpu_buffer_rsrc_t r, unsigned v
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int KS, int NF, bool LORA, int PRO>
+// FP8 (BASELINE configs[4]: fp8 projection GEMMs): the same kernel with OCP e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 -
+//   * weights arrive pre-quantised, one f32 scale per output channel (g.w8 / g.w_scale, packed at finalize);
+//   * the resident rows are loaded (and LayerNorm'ed) in bf16 as before, then quantised IN REGISTERS with one scale per row
+//     (amax over the row by two cross-lane maxima): 8 fp8 per lane and k-step = 2 VGPRs instead of 4;
+//   * weight chunks are half the bytes (BN x K bytes: 20 KB at K = 320), fragment reads are ds_read_b64;
+//   * the accumulators are rescaled by row scale x channel scale after the K loop, before the (bf16) LoRA up-projection step
+//     and the bias; everything after that is the bf16 kernel's epilogue.
+typedef long rp_f8x8;  // 8 fp8 (one MFMA operand)
+__device__ __forceinline__ rp_f8x8 rp_quant8(const bf16x8& x, float inv_scale) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)x[0] * inv_scale, (float)x[1] * inv_scale, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)x[2] * inv_scale, (float)x[3] * inv_scale, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)x[4] * inv_scale, (float)x[5] * inv_scale, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)x[6] * inv_scale, (float)x[7] * inv_scale, hi, true);
+    return (rp_f8x8)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int KS, int NF, bool LORA, int PRO, bool FP8>
 __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     typedef bf16 T;
     constexpr int K = KS * 32, BN = NF * 16, BM = 128, MF = 2;
-    constexpr int CPR = KS * 4;                 // 16-byte chunks per weight row
-    constexpr int CHUNK = BN * K * 2;           // bytes of one weight chunk in LDS
+    constexpr int EW = FP8 ? 1 : 2;             // bytes per weight element
+    constexpr int CPR = KS * 4 / (FP8 ? 2 : 1); // 16-byte chunks per weight row
+    constexpr int CHUNK = BN * K * EW;          // bytes of one weight chunk in LDS
+    constexpr int SWZ = FP8 ? 3 : 7;            // 16-byte chunk swizzle: c ^ (f(row) & SWZ); fp8 rows are 320 / 640 B: f = row >> 2
     constexpr int PIECES = BN * CPR / 64;       // 1-KiB LDS-DMA pieces per chunk
     constexpr int PPW = (PIECES + 3) / 4;       // pieces per wave
     static_assert((BN * CPR) % 64 == 0, "whole DMA pieces");
@@ -1255,12 +1274,14 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     if (c_beg >= c_end) return;
 
     const T* ap = reinterpret_cast<const T*>(g.a0);
-    const T* wp = reinterpret_cast<const T*>(g.w);
+    const void* wp = FP8 ? g.w8 : g.w;
+    const void* lp = FP8 ? g.lora_a8 : g.lora_a;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(ap, (unsigned)min((long long)g.M * g.lda0 * 2, 0x7FFFFFFFll));
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)min((long long)g.N * K * 2, 0x7FFFFFFFll));
-    const __amdgpu_buffer_rsrc_t rl = make_rsrc(LORA ? g.lora_a : (const void*)wp, LORA ? (unsigned)((long long)g.lora_R * K * 2) : 0u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)min((long long)g.N * K * EW, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(LORA ? lp : wp, LORA ? (unsigned)((long long)g.lora_R * K * EW) : 0u);
+    auto swz = [](int row) { return FP8 ? ((row >> 2) & 3) : (row & 7); };
 
-    // ---- weight chunk DMA geometry: LDS position L (16-byte units) = row * CPR + (c ^ (row & 7)) ----
+    // ---- weight chunk DMA geometry: LDS position L (16-byte units) = row * CPR + (c ^ swz(row)) ----
     static_assert(PIECES % 4 == 0, "every wave issues the same number of DMA pieces (no control flow around them: the compiler's\n"
                                    "wait-count model turns conditional VMEM issue into vmcnt(0) drains)");
     unsigned wvo[PPW];
@@ -1268,13 +1289,13 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     for (int p = 0; p < PPW; ++p) {
         const int L = (p * 4 + wave) * 64 + lane;
         const int row = L / CPR, cs = L - row * CPR;
-        const int c = cs ^ (row & 7);
-        wvo[p] = (unsigned)((row * K + c * 8) * 2);
+        const int c = cs ^ swz(row);
+        wvo[p] = (unsigned)(row * K * EW + c * 16);
     }
     // `live` false: the chunk does not exist - every lane's offset lies beyond num_records, the DMA writes zeros (harmless)
     auto stage_w = [&](int chunk, int buf, bool live) {
         char* sb = smem + buf * CHUNK;
-        const unsigned base = live ? (unsigned)chunk * (unsigned)(BN * K * 2) : 0xC0000000u;  // rows past N also lie beyond num_records
+        const unsigned base = live ? (unsigned)chunk * (unsigned)CHUNK : 0xC0000000u;  // rows past N also lie beyond num_records
 #pragma unroll
         for (int p = 0; p < PPW; ++p) bl16(rw, sb + (p * 4 + wave) * 1024, wvo[p], base);
     };
@@ -1298,8 +1319,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
             const int piece = p * 4 + wave;
             const int L = piece * 64 + lane;
             const int row = L / CPR, cs = L - row * CPR;
-            const int c = cs ^ (row & 7);
-            const unsigned vo = (piece < LPIECES && row < g.lora_R) ? (unsigned)((row * K + c * 8) * 2) : BL_OOB;
+            const int c = cs ^ swz(row);
+            const unsigned vo = (piece < LPIECES && row < g.lora_R) ? (unsigned)(row * K * EW + c * 16) : BL_OOB;
             if (piece < LPIECES) bl16(rl, smem + CHUNK + piece * 1024, vo, 0u);
         }
     }
@@ -1350,21 +1371,59 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
         }
     }
 
+    // ---- FP8: quantise the resident rows, one scale per row (amax / 448, the e4m3 maximum) ----
+    rp_f8x8 a8[FP8 ? MF : 1][FP8 ? KS : 1];
+    float sa[MF] = {1.f, 1.f};
+    if (FP8) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            float am = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf((float)af[j][kk][e]));
+            am = fmaxf(am, __shfl_xor(am, 16));
+            am = fmaxf(am, __shfl_xor(am, 32));
+            sa[j] = fmaxf(am, 1e-20f) * (1.0f / 448.0f);
+            const float inv = 1.0f / sa[j];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a8[j][kk] = rp_quant8(af[j][kk], inv);
+        }
+    }
+    // weight fragment of lane (fr, fg) for k-step kk out of an LDS image with row pitch K * EW (base: row 0 of the fragment)
+    auto wfrag_off = [&](int kk) {
+        if (FP8) return (((kk * 2 + (fg >> 1)) ^ swz(fr)) * 16) + (fg & 1) * 8;
+        return ((kk * 4 + fg) ^ swz(fr)) * 16;
+    };
+
     // ---- LoRA: z = x A^T from the resident rows (one 16-column "chunk"), kept in registers as the row operand of the
     // up-projection step: lane (fr, fg) holds z[m = fr][q = 4 fg + r], which it uses as k elements 0..3 of its k group
     bf16x8 zf[MF];
     if (LORA) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* sl = smem + CHUNK;
+        const char* sl = smem + CHUNK + fr * (K * EW);
         f32x4 zacc[MF];
 #pragma unroll
         for (int j = 0; j < MF; ++j) zacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 lf = *reinterpret_cast<const bf16x8*>(sl + fr * (K * 2) + (((kk * 4 + fg) ^ (fr & 7)) * 16));
+            if constexpr (FP8) {
+                const rp_f8x8 lf = *reinterpret_cast<const rp_f8x8*>(sl + wfrag_off(kk));
 #pragma unroll
-            for (int j = 0; j < MF; ++j) zacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[j][kk], zacc[j], 0, 0, 0);
+                for (int j = 0; j < MF; ++j) zacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(lf, a8[j][kk], zacc[j], 0, 0, 0);
+            } else {
+                const bf16x8 lf = *reinterpret_cast<const bf16x8*>(sl + wfrag_off(kk));
+#pragma unroll
+                for (int j = 0; j < MF; ++j) zacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, af[j][kk], zacc[j], 0, 0, 0);
+            }
+        }
+        if (FP8) {  // back to real units: row scale x the adapter rows' own scales (q = 4 fg + r)
+            const f32x4 las = *reinterpret_cast<const f32x4*>(g.lora_a_scale + fg * 4);
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zacc[j][r] *= sa[j] * las[r];
         }
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
@@ -1385,7 +1444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     constexpr int OPITCH = BN + 8;      // wave-private row tile [32][OPITCH]
     constexpr int TPITCH = 32 + 8;      // wave-private transposed tile [BN][TPITCH] (V^T)
     constexpr int GP = BN / 2 + 8;      // GEGLU tile [32][GP]
-    constexpr int WREG = 8192;          // bytes of a wave's staging region inside the chunk's own (consumed) weight buffer
+    constexpr int WREG = CHUNK / 4;     // bytes of a wave's staging region inside the chunk's own (consumed) weight buffer
     static_assert(32 * OPITCH * 2 <= WREG && BN * TPITCH * 2 <= WREG && 4 * WREG <= CHUNK, "staging regions");
     const int wm0 = wave * 32;
     const bool full_m = m0 + BM <= g.M;
@@ -1404,10 +1463,17 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
         float pb[NF][4];
 #pragma unroll
         for (int i = 0; i < NF; ++i) load4<float>(g.bias + min(n0 + i * 16 + fg * 4, g.N - 4), pb[i]);  // (launch_rp: never null)
+        float sw[FP8 ? NF : 1][4];
+        if (FP8) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) load4<float>(g.w_scale + min(n0 + i * 16 + fg * 4, g.N - 4), sw[i]);
+        }
         // counted wait only when every DMA instruction of chunk c is in range (a fully out-of-range LDS-DMA instruction retires
-        // out of order and would satisfy the count early) and the store count is known; the NF bias loads above are younger
-        const int young = pending > 0 && n0 + BN <= g.N ? pending + NF : 0;
-        if (young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // out of order and would satisfy the count early) and the store count is known; the NF bias (+ NF scale) loads above are younger
+        const int young = pending > 0 && n0 + BN <= g.N ? pending + (FP8 ? 2 * NF : NF) : 0;
+        if (young == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (young == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (young == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -1427,27 +1493,56 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
             }
         }
         f32x4 acc[NF][MF];
-        const char* sw = smem + buf * CHUNK + fr * (K * 2);
+        const char* sw_l = smem + buf * CHUNK + fr * (K * EW);
         // weight fragments software-pipelined one k-step ahead; the scheduling barriers keep the compiler from hoisting all
         // KS*NF LDS reads above the MFMAs (it would need the whole register file)
-        bf16x8 wf[2][NF];
-        auto load_w = [&](bf16x8 (&dst)[NF], int kk) {
-            const int phys = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+        if constexpr (FP8) {
+            rp_f8x8 wf[2][NF];
+            auto load_w = [&](rp_f8x8 (&dst)[NF], int kk) {
+                const int off = wfrag_off(kk);
 #pragma unroll
-            for (int i = 0; i < NF; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(sw + i * 16 * (K * 2) + phys);
-        };
-        load_w(wf[0], 0);
+                for (int i = 0; i < NF; ++i) dst[i] = *reinterpret_cast<const rp_f8x8*>(sw_l + i * 16 * K + off);
+            };
+            load_w(wf[0], 0);
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+            for (int kk = 0; kk < KS; ++kk) {
+                if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int j = 0; j < MF; ++j) {
+                        const f32x4 cz = kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[kk & 1][i], a8[j][kk], cz, 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // real units: row scale x channel scale, then the bias (the bf16 kernel starts its accumulators at the bias instead)
 #pragma unroll
             for (int i = 0; i < NF; ++i)
 #pragma unroll
-                for (int j = 0; j < MF; ++j) {
-                    const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc[i][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], af[j][kk], cz, 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < MF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(acc[i][j][r], sa[j] * sw[i][r], pb[i][r]);
+        } else {
+            bf16x8 wf[2][NF];
+            auto load_w = [&](bf16x8 (&dst)[NF], int kk) {
+                const int off = wfrag_off(kk);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(sw_l + i * 16 * (K * 2) + off);
+            };
+            load_w(wf[0], 0);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int j = 0; j < MF; ++j) {
+                        const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc[i][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], af[j][kk], cz, 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (g.dbg & 128) {  // probe: no epilogue / stores
             if (acc[0][0][0] == 1.2345e30f) reinterpret_cast<float*>(g.out)[0] = acc[1][1][1] + acc[NF - 1][0][2];
@@ -1823,26 +1918,32 @@ static int launch_ws(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
-// row-panel configurations: id -> <KS, NF>   (K = 32*KS, weight chunks of 16*NF output columns x K = 40 KB)
-#define RP_CFGS(X)   \
-    X(60, 10, 4)     \
-    X(61, 20, 2)
+// row-panel configurations: id -> <KS, NF, FP8>   (K = 32*KS; weight chunks of 16*NF output columns x K: 40 KB bf16, 20 / 40 KB fp8)
+#define RP_CFGS(X)        \
+    X(60, 10, 4, false)   \
+    X(61, 20, 2, false)   \
+    X(62, 10, 4, true)    \
+    X(63, 20, 4, true)
 
-static void rp_dims(int tile, int* ks, int* nf) {
+static void rp_dims(int tile, int* ks, int* nf, bool* fp8) {
     *ks = *nf = 0;
+    *fp8 = false;
     switch (tile) {
-#define X(id, k, n) case id: *ks = k; *nf = n; break;
+#define X(id, k, n, f) case id: *ks = k; *nf = n; *fp8 = f; break;
         RP_CFGS(X)
 #undef X
     }
 }
 static bool rp_ok(const GemmArgs& g, int tile) {
     int ks, nf;
-    rp_dims(tile, &ks, &nf);
+    bool fp8;
+    rp_dims(tile, &ks, &nf, &fp8);
     const int bn = nf * 16;
     if (!ks || g.no_rp || g.conv || g.c1 || g.a1 || g.batch != 1 || g.heads != 1 || g.splitk > 1) return false;
     if (g.K != 32 * ks || g.lda0 % 8 != 0 || g.N % 16 != 0 || g.M < 1) return false;
     if (g.alpha != 1.0f || g.rowvec || g.lora_z || (!g.bias && (size_t)g.N * sizeof(float) > kZeroPageBytes)) return false;
+    if (fp8 != (g.w8 != nullptr)) return false;  // fp8 operands are a property of the launch (packed weights), never a tuner choice
+    if (fp8 && (!g.w_scale || (g.lora_a && (!g.lora_a8 || !g.lora_a_scale)))) return false;
     if (g.act == ACT_GEGLU) {
         if (g.N % 32 != 0 || (nf & 1) || g.out_mode != OUT_ROWS || g.ldo % 8 != 0 || g.resid) return false;
     } else if (g.act != ACT_NONE) {
@@ -1858,33 +1959,34 @@ static bool rp_ok(const GemmArgs& g, int tile) {
     if (g.lora_a && (g.lora_r != 4 || g.lora_R > 16 || !g.lora_b || g.act == ACT_GEGLU)) return false;
     return (long long)g.M * g.lda0 * 2 < 0x7FFFFFFFll && (long long)g.N * g.K * 2 < 0x7FFFFFFFll;
 }
-// the row-panel configuration for this K (0: none)
+// the row-panel configuration for this K (0: none); fp8 operands (g.w8) select the fp8 configurations
 int gemm_rp_tile(const GemmArgs& g) {
     static const int env = [] { const char* e = getenv("MRISR_RP"); return e ? atoi(e) : 1; }();
     if (!env) return 0;
-#define X(id, k, n) if (g.K == 32 * k && rp_ok(g, id)) return id;
+#define X(id, k, n, f) if (g.K == 32 * k && rp_ok(g, id)) return id;
     RP_CFGS(X)
 #undef X
     return 0;
 }
-template <int KS, int NF>
+template <int KS, int NF, bool FP8>
 static int launch_rp(const GemmArgs& g, hipStream_t st) {
     constexpr int K = KS * 32, BN = NF * 16;
-    constexpr int smem = 2 * BN * K * 2;
-    MRISR_REQUIRE(rp_ok(g, KS == 10 ? 60 : 61), "row-panel kernel: plain un-split bf16 row GEMM with K = 32*KS");
+    constexpr int smem = 2 * BN * K * (FP8 ? 1 : 2);
+    constexpr int tile_id = FP8 ? (KS == 10 ? 62 : 63) : (KS == 10 ? 60 : 61);
+    MRISR_REQUIRE(rp_ok(g, tile_id), "row-panel kernel: plain un-split bf16 row GEMM with K = 32*KS (fp8: packed weights + scales)");
     static bool attr = false;
     if (!attr) {
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 0, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 1, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 0, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 1, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
     const int panels = (g.M + 127) / 128, nchunks = (g.N + BN - 1) / BN;
     static const int ys_env = [] { const char* e = getenv("MRISR_RP_YSPLIT"); return e ? atoi(e) : 0; }();
     int ysplit = ys_env > 0 ? ys_env : (512 + panels / 2) / panels;  // ~2 workgroups per CU
     ysplit = std::max(1, std::min(ysplit, nchunks));
-    static const std::string base_name = std::string("gemm_bf16_rp") + std::to_string(K) + "x" + std::to_string(BN);
+    static const std::string base_name = std::string(FP8 ? "gemm_fp8_rp" : "gemm_bf16_rp") + std::to_string(K) + "x" + std::to_string(BN);
     std::string pname = base_name;
     if (prof_enabled() && prof_shapes()) {
         char buf[160];
@@ -1894,7 +1996,7 @@ static int launch_rp(const GemmArgs& g, hipStream_t st) {
     double fl = g.alg_flops, by = g.alg_bytes;
     if (prof_enabled()) {
         if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K;
-        if (by == 0.0) by = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+        if (by == 0.0) by = 2.0 * ((double)g.M * g.K + (double)g.M * g.N) + (FP8 ? 1.0 : 2.0) * (double)g.N * g.K;
     }
     ProfScope ps(prof_intern(pname), fl, by, st);
     const dim3 grid(panels, ysplit);
@@ -1905,11 +2007,11 @@ static int launch_rp(const GemmArgs& g, hipStream_t st) {
     }
     if (g.ln_gamma) {
         MRISR_REQUIRE(g.ln_beta, "LayerNorm prologue: gamma and beta");
-        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 1>), grid, dim3(256), smem, st, g);
-        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 1>), grid, dim3(256), smem, st, g);
+        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 1, FP8>), grid, dim3(256), smem, st, g);
+        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 1, FP8>), grid, dim3(256), smem, st, g);
     } else {
-        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 0>), grid, dim3(256), smem, st, g);
-        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 0>), grid, dim3(256), smem, st, g);
+        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 0, FP8>), grid, dim3(256), smem, st, g);
+        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 0, FP8>), grid, dim3(256), smem, st, g);
     }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -2061,7 +2163,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
     // 50-52 (weight-stationary short-K kernels) are NOT candidates: correct, but 30-60 % slower than the tiled kernels on
     // every shape they fit (profiles/r01b_ws_sweep.log: one A fragment per wave makes them LDS-read bound); kept for the record
-    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45, 60, 61};  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
+    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45, 60, 61};  // (62, 63: fp8 operands, chosen by the launch, not the tuner)  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
         {   // debugging aid: MRISR_TUNE_SKIP="41,43" removes candidates
@@ -2133,10 +2235,10 @@ extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
 
 int gemm_choose(GemmArgs& g, bool is_bf16) {
     int t = 0, s = 1;
-    if (g.ln_gamma) {  // a fused LayerNorm prologue exists only in the row-panel kernel (the caller checked gemm_rp_tile)
+    if (g.ln_gamma || g.w8) {  // a fused LayerNorm prologue / fp8 operands exist only in the row-panel kernel (the caller checked gemm_rp_tile)
         g.tile = gemm_rp_tile(g);
         g.splitk = 1;
-        MRISR_REQUIRE(g.tile != 0, "LayerNorm prologue needs the row-panel kernel");
+        MRISR_REQUIRE(g.tile != 0, "LayerNorm prologue / fp8 operands need the row-panel kernel");
         return 0;
     }
     if (g_force_tile) { g.tile = g_force_tile; if (g.splitk < 1) g.splitk = 1; return 0; }
@@ -2202,7 +2304,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 #define X(id, ks, nb) case id: rc = launch_ws<ks, nb>(g, st); break;
         WS_CFGS(X)
 #undef X
-#define X(id, ks, nf) case id: rc = launch_rp<ks, nf>(g, st); break;
+#define X(id, ks, nf, f8) case id: rc = launch_rp<ks, nf, f8>(g, st); break;
         RP_CFGS(X)
 #undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;

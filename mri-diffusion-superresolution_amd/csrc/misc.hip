@@ -828,6 +828,33 @@ int launch_resshift_forward(const float* hr, const float* lr, const float* noise
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) row quantisation of packed bf16 weights: one wave per row, scale = amax / 448 (BASELINE configs[4])
+// ------------------------------------------------------------------------------------------------
+__global__ void quant_rows_fp8_kernel(const bf16* __restrict__ src, int rows, int cols, unsigned char* __restrict__ dst, float* __restrict__ scales) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bf16* s = src + (size_t)row * cols;
+    float am = 0.f;
+    for (int c = lane; c < cols; c += 64) am = fmaxf(am, fabsf((float)s[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    const float sc = fmaxf(am, 1e-20f) * (1.0f / 448.0f), inv = 1.0f / sc;
+    if (lane == 0) scales[row] = sc;
+    unsigned short* d = reinterpret_cast<unsigned short*>(dst + (size_t)row * cols);
+    for (int c = lane * 2; c < cols; c += 128) {
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32((float)s[c] * inv, (float)s[c + 1] * inv, 0, false);
+        d[c >> 1] = (unsigned short)(pk & 0xFFFF);
+    }
+}
+int launch_quant_rows_fp8(const void* src_bf16, int rows, int cols, void* dst8, float* scales, hipStream_t st) {
+    MRISR_REQUIRE(cols % 2 == 0, "fp8 row quantisation: even column count");
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, reinterpret_cast<const bf16*>(src_bf16), rows, cols,
+                       reinterpret_cast<unsigned char*>(dst8), scales);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 #define INST(T)                                                                                                    \
     template int launch_gemv_rows<T>(const float*, int, const void*, const float*, float*, int, int, int, int, int, \
                                      hipStream_t);                                                                 \

@@ -196,6 +196,21 @@ struct Packer {
             row += n;
         }
         l.b = bias;
+        // fp8 copies (BASELINE configs[4]): the short-K projections the row-panel kernel serves
+        // (fp8_linears 1: K = 320 only - at K = 640 the fp8 kernel's resident rows + their fp8 copy spill and it loses to the bf16
+        // kernels, profiles/r02e_shape_fp8.log; 2: both widths)
+        if (m.cfg.fp8_linears && sizeof(T) == 2 && (k == 320 || (k == 640 && m.cfg.fp8_linears >= 2)) && ntot % 16 == 0) {
+            l.w8 = m.new_packed((size_t)ntot * k, false);
+            l.w_scale = static_cast<float*>(m.new_packed((size_t)ntot * sizeof(float), true));
+            if (!l.w8 || !l.w_scale) { err = 4; return l; }
+            if (launch_quant_rows_fp8(l.w, ntot, k, l.w8, l.w_scale, st)) err = 5;
+            if (l.R && l.R <= 16) {
+                l.loraA8 = m.new_packed((size_t)16 * k, true);
+                l.loraA_scale = static_cast<float*>(m.new_packed(16 * sizeof(float), true));
+                if (!l.loraA8 || !l.loraA_scale) { err = 4; return l; }
+                if (launch_quant_rows_fp8(l.loraA, l.R, k, l.loraA8, l.loraA_scale, st)) err = 5;
+            }
+        }
         return l;
     }
     // host-side helper for merged mode (load time only): W' = W + s*B*A via a tiny kernel

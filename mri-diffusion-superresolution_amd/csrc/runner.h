@@ -116,6 +116,13 @@ struct Runner {
         if (g.out_mode != OUT_HEADS) { g.out = out; g.ldo = ldo; }
         // the row-panel kernel fuses LoRA only in the in-kernel rank-4 form
         if (lw.R && !(lw.r == 4 && lw.R <= 16 && lora_in_kernel())) g.no_rp = 1;
+        // fp8 operands (cfg.fp8_linears; inference only): when the row-panel fp8 kernel takes this launch
+        if (lw.w8 && sizeof(T) == 2 && !m.keep && !g.no_rp) {
+            GemmArgs probe = g;
+            probe.w8 = lw.w8; probe.w_scale = lw.w_scale;
+            if (lw.R) { probe.lora_a = lw.loraA; probe.lora_b = lw.loraB; probe.lora_r = lw.r; probe.lora_R = lw.R; probe.lora_a8 = lw.loraA8; probe.lora_a_scale = lw.loraA_scale; }
+            if (gemm_rp_tile(probe)) { g.w8 = lw.w8; g.w_scale = lw.w_scale; g.lora_a8 = lw.loraA8; g.lora_a_scale = lw.loraA_scale; }
+        }
         if (ln) {
             MRISR_REQUIRE(ln->c == lw.k && lda == lw.k, "LayerNorm width vs the projection's K");
             GemmArgs probe = g;  // eligibility as the launch will see it (the in-kernel LoRA form, rank 4, is part of it)

@@ -83,6 +83,11 @@ struct LinW {  // packed [n][k] in compute dtype, bias f32 (GEGLU: interleaved)
     int r = 0, R = 0, secN = 1;
     void* loraA = nullptr;
     const float* loraB = nullptr;
+    // fp8 copies for the row-panel kernel (cfg.fp8_linears; K = 320 / 640 only): e4m3 rows + one f32 scale per row
+    void* w8 = nullptr;
+    float* w_scale = nullptr;
+    void* loraA8 = nullptr;       // [16][k] (rows >= R zero)
+    float* loraA_scale = nullptr; // [16]
     // training
     std::vector<std::string> mod_names;  // the fused modules, in column order (e.g. attn1.to_q, to_k, to_v)
     std::vector<int> mod_lora;           // 1 if that module carries an adapter

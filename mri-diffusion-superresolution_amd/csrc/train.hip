@@ -171,6 +171,8 @@ int Model::lora_refresh(hipStream_t st) {
                 hipLaunchKernelGGL(lora_refresh_kernel<bf16>, dim3(blocks), dim3(256), 0, st, A, B, static_cast<bf16*>(l->loraA), l->loraAT,
                                    l->loraB_rw, static_cast<bf16*>(l->loraBT), l->r, l->R, l->k, l->secN, l->n, (int)j, row0, lora_scale);
         }
+        // the fp8 copy of the adapters' A rows (inference through the fp8 projections after training steps)
+        if (l->loraA8 && cfg.compute_dtype != MRISR_F32) TRY(launch_quant_rows_fp8(l->loraA, l->R, l->k, l->loraA8, l->loraA_scale, st));
     }
     MRISR_CHECK_HIP(hipGetLastError());
     ctx_valid = false;  // cached cross-attention K / V depend on attn2.to_k / to_v adapters

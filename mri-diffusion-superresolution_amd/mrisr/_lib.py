@@ -30,7 +30,7 @@ class UNetCfg(C.Structure):
                 ("layers_per_block", C.c_int32), ("num_heads", C.c_int32), ("cross_attention_dim", C.c_int32),
                 ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float), ("cond_channels", C.c_int32),
                 ("cond_embed_channels", C.c_int32 * 4), ("compute_dtype", C.c_int32), ("lora_rank", C.c_int32),
-                ("lora_fused", C.c_int32), ("flash_attention", C.c_int32)]
+                ("lora_fused", C.c_int32), ("flash_attention", C.c_int32), ("fp8_linears", C.c_int32)]
 
 
 class AdapterCfg(C.Structure):
@@ -68,7 +68,7 @@ EXPORTS = [
     "mrisr_train_prepare", "mrisr_train_num_trainable", "mrisr_train_num_tensors", "mrisr_train_tensor_info",
     "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_train_set_intrablock_grads", "mrisr_optim_sumsq", "mrisr_optim_adamw", "mrisr_optim_ema",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
-    "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_ln_linear", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
+    "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_ln_linear", "mrisr_op_linear_fp8", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
     "mrisr_op_attention_bwd",
 ]
 

@@ -65,7 +65,7 @@ class _ControlNetOutput:
         self.mid_block_res_sample = mid
 
 
-def _c_cfg(cfg: UNetConfig, compute_dtype, lora_rank, lora_fused, flash) -> L.UNetCfg:
+def _c_cfg(cfg: UNetConfig, compute_dtype, lora_rank, lora_fused, flash, fp8=False) -> L.UNetCfg:
     c = L.UNetCfg()
     c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
     c.num_levels = len(cfg.block_out_channels)
@@ -84,6 +84,7 @@ def _c_cfg(cfg: UNetConfig, compute_dtype, lora_rank, lora_fused, flash) -> L.UN
     c.lora_rank = lora_rank
     c.lora_fused = 1 if lora_fused else 0
     c.flash_attention = 1 if flash else 0
+    c.fp8_linears = 2 if fp8 == "all" else (1 if fp8 else 0)  # True: the K = 320 projections; "all": K = 320 and 640
     return c
 
 
@@ -92,7 +93,7 @@ class _DeviceModel:
     _create = None
 
     def __init__(self, config=None, compute_dtype="bf16", lora_rank: int = 0, lora_alpha: Optional[float] = None,
-                 lora_fused: bool = True, flash_attention: bool = True, device="cuda"):
+                 lora_fused: bool = True, flash_attention: bool = True, device="cuda", fp8=False):
         if not torch.cuda.is_available():
             raise L.MrisrError("mrisr needs an AMD GPU (gfx950); there is no CPU fallback")
         cfg = config if isinstance(config, UNetConfig) else (UNetConfig() if config is None else UNetConfig.from_oracle_like(config))
@@ -103,7 +104,10 @@ class _DeviceModel:
         self.lora_scale = (lora_alpha / lora_rank) if (lora_rank and lora_alpha is not None) else 1.0
         self._params: Dict[str, torch.Tensor] = {}
         self._h = C.c_void_p()
-        self._ccfg = _c_cfg(cfg, compute_dtype, lora_rank, lora_fused, flash_attention)
+        if fp8 and L.dtype_id(compute_dtype) != L.MRISR_BF16:
+            raise ValueError("fp8 projections are a mode of the bf16 engine")
+        self.fp8 = bool(fp8)
+        self._ccfg = _c_cfg(cfg, compute_dtype, lora_rank, lora_fused, flash_attention, fp8)
         L.check(getattr(L.lib(), self._create)(C.byref(self._ccfg), C.byref(self._h)))
         self._finalized = False
         self.training = False

@@ -68,6 +68,22 @@ def ln_linear(x, gamma, beta, weight, bias=None, act=L.ACT_NONE):
     return y
 
 
+def linear_fp8(x, weight, bias=None, act=L.ACT_NONE, gamma=None, beta=None):
+    """[LayerNorm(x)] W^T + bias with OCP e4m3 operands on the fp8 MFMA (row-panel kernel; bf16 in / out, K = 320 / 640)."""
+    x = x.contiguous()
+    w = weight.detach().to(torch.float32).contiguous()
+    b = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+    ga = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
+    be = beta.detach().to(torch.float32).contiguous() if beta is not None else None
+    n = w.shape[0]
+    y = torch.empty((x.shape[0], n // 2 if act == L.ACT_GEGLU else n), dtype=x.dtype, device=x.device)
+    tx, ty = L.as_tensor(x), L.as_tensor(y)
+    L.check(L.lib().mrisr_op_linear_fp8(C.byref(tx), C.c_void_p(ga.data_ptr()) if ga is not None else None,
+                                        C.c_void_p(be.data_ptr()) if be is not None else None, C.c_void_p(w.data_ptr()),
+                                        C.c_void_p(b.data_ptr()) if b is not None else None, n, act, C.byref(ty), L.stream_ptr()))
+    return y
+
+
 def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None):
     xb, tx = _nhwc(x)
     t2 = None

@@ -259,13 +259,43 @@ def _b(p: Params, name: str) -> Optional[Tensor]:
     return p.get(name + ".base_layer.bias")
 
 
+# BASELINE configs[4] (fp8 projection GEMMs): when set, ``FP8_LINEARS(name, K) -> bool`` selects the linears / 1x1 projections
+# that run with fake-quantised OCP e4m3 operands.  "parity unpinned": the reference has no fp8 path (its only reduced-precision
+# hook is ``mixed_precision: "fp16"``, nb ResDif c11:38); this restates the scheme the product implements so that its tolerance
+# is principled - one scale per weight row (output channel) and per activation row, amax / 448, round-to-nearest-even to
+# ``torch.float8_e4m3fn``, exact accumulation.  The LoRA down-projection rows are quantised the same way; the rank-r
+# up-projection stays in full precision.
+FP8_LINEARS = None
+
+
+def fp8_fake_quant_rows(t: Tensor) -> Tensor:
+    s = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-20) / 448.0
+    return (t / s).to(torch.float8_e4m3fn).to(t.dtype) * s
+
+
 def linear(p: Params, name: str, x: Tensor, lora_scale: float = 1.0) -> Tensor:
     """y = x W^T + b  (+ (alpha/r) (x A^T) B^T when LoRA tensors for ``name`` are present; a7)."""
-    y = F.linear(x, _w(p, name), _b(p, name))
+    w = _w(p, name)
     ka = name + ".lora_A.default.weight"
+    fp8 = FP8_LINEARS is not None and FP8_LINEARS(name, x.shape[-1])
+    if fp8:
+        x, w = fp8_fake_quant_rows(x), fp8_fake_quant_rows(w)
+    y = F.linear(x, w, _b(p, name))
     if ka in p:
-        y = y + lora_scale * F.linear(F.linear(x, p[ka]), p[name + ".lora_B.default.weight"])
+        a = fp8_fake_quant_rows(p[ka]) if fp8 else p[ka]
+        y = y + lora_scale * F.linear(F.linear(x, a), p[name + ".lora_B.default.weight"])
     return y
+
+
+def proj1x1(p: Params, name: str, x: Tensor) -> Tensor:
+    """proj_in / proj_out of Transformer2DModel: 1x1 convs = a linear over the channel vector of every pixel."""
+    if FP8_LINEARS is not None and FP8_LINEARS(name, x.shape[1]):
+        B, C, H, W = x.shape
+        w = p[name + ".weight"].reshape(-1, C)
+        rows = fp8_fake_quant_rows(x.permute(0, 2, 3, 1).reshape(-1, C))
+        y = F.linear(rows, fp8_fake_quant_rows(w), p.get(name + ".bias"))
+        return y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+    return conv(p, name, x, padding=0)
 
 
 def conv(p: Params, name: str, x: Tensor, stride: int = 1, padding: int = 1) -> Tensor:
@@ -307,7 +337,7 @@ def transformer_2d(p: Params, name: str, x: Tensor, ctx: Tensor, cfg: UNetConfig
     B, C, H, W = x.shape
     res = x
     h = group_norm(p, name + ".norm", x, cfg.norm_num_groups, 1e-6)
-    h = conv(p, name + ".proj_in", h, padding=0)
+    h = proj1x1(p, name + ".proj_in", h)
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     b = name + ".transformer_blocks.0"
     n1 = layer_norm(p, b + ".norm1", h)
@@ -317,7 +347,7 @@ def transformer_2d(p: Params, name: str, x: Tensor, ctx: Tensor, cfg: UNetConfig
     u, g = ff.chunk(2, dim=-1)
     h = h + linear(p, b + ".ff.net.2", u * F.gelu(g))
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-    return conv(p, name + ".proj_out", h, padding=0) + res
+    return proj1x1(p, name + ".proj_out", h) + res
 
 
 def time_embed(p: Params, t: Tensor, batch: int, cfg: UNetConfig, dtype) -> Tensor:

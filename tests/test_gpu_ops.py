@@ -327,6 +327,91 @@ def test_row_panel_kernel_many_workgroups_repeatable(M, N):
         assert rel(a, u * F.gelu(gg)) < TOL["bf16"] and torch.equal(a, ops.ln_linear(xc, gc, bec, wc, bc, act=L.ACT_GEGLU))
 
 
+def _fq(t):
+    """e4m3 fake-quant with one scale per row (the scheme of the fp8 projections; oracle.unet.fp8_fake_quant_rows)."""
+    sc = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-20) / 448.0
+    return (t / sc).to(torch.float8_e4m3fn).float() * sc
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 320, 320), (4096, 960, 320), (200, 336, 320), (8192 + 40, 320, 320), (1000, 2560, 320),
+                                   (256, 640, 640), (4096 + 16, 1920, 640), (130, 48, 640)])
+def test_linear_fp8_row_panel_kernel(M, N, K):
+    """BASELINE configs[4]: the fp8 (OCP e4m3, v_mfma_f32_16x16x32_fp8_fp8) form of the row-panel kernel.  Against the SAME
+    quantisation done in torch (per-row activation scales, per-channel weight scales, exact accumulation) the kernel must be as
+    close as the bf16 kernel is to its reference - that pins the operand layout, the scales and the epilogue; against the
+    unquantised product the error is the fp8 quantisation error itself (3 mantissa bits: a few percent)."""
+    from mrisr import _lib as L
+    from mrisr import ops
+    x, w, b = _rnd((M, K), "bf16", 81), _rnd((N, K), "f32", 82, K ** -0.5), _rnd((N,), "f32", 83)
+    wq = w.to(torch.bfloat16).float()
+    exact = F.linear(x.float(), wq, b)
+    ref8 = F.linear(_fq(x.float()), _fq(wq), b)
+    got = ops.linear_fp8(x.cuda(), w.cuda(), b.cuda())
+    assert rel(got, ref8) < TOL["bf16"], rel(got, ref8)
+    assert 5e-3 < rel(got, exact) < 8e-2, rel(got, exact)          # fp8 really ran, and its error is the expected size
+    assert rel(ops.linear_fp8(x.cuda(), w.cuda(), None), F.linear(_fq(x.float()), _fq(wq))) < TOL["bf16"]
+    if N % 32 == 0:
+        u, g = ref8.chunk(2, dim=-1)
+        assert rel(ops.linear_fp8(x.cuda(), w.cuda(), b.cuda(), act=L.ACT_GEGLU), u * F.gelu(g)) < TOL["bf16"]
+    # LayerNorm prologue in front of the quantisation
+    xo = (x.float() * 0.5 + 3.0).to(torch.bfloat16)
+    ga, be = 1 + 0.1 * _rnd((K,), "f32", 84), 0.1 * _rnd((K,), "f32", 85)
+    xn = F.layer_norm(xo.float(), (K,), ga, be, 1e-5).to(torch.bfloat16).float()
+    got = ops.linear_fp8(xo.cuda(), w.cuda(), b.cuda(), gamma=ga.cuda(), beta=be.cuda())
+    assert rel(got, F.linear(_fq(xn), _fq(wq), b)) < TOL["bf16"]
+    assert torch.equal(got, ops.linear_fp8(xo.cuda(), w.cuda(), b.cuda(), gamma=ga.cuda(), beta=be.cuda()))
+
+
+def test_unet_fp8_projections_match_fake_quant_oracle():
+    """SD-1.5 channel widths (320 / 640, the widths the fp8 projections serve) + rank-4 LoRA: the engine with fp8_linears against
+    the oracle with the same linears fake-quantised (oracle.unet.FP8_LINEARS), within the bf16 engine's own bound; and the fp8
+    kernels really ran (profiler classes)."""
+    import json
+
+    import ctypes as C
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg = ou.UNetConfig(block_out_channels=(320, 640), attn_levels=(True, True), cross_attention_dim=64)
+    up = ou.init_unet_params(cfg, seed=171, perturb_norm=True)
+    lora = ou.init_lora_params(up, rank=4, seed=172)
+    p = {**up, **lora}
+    g = torch.Generator().manual_seed(173)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, 64), generator=g)
+    t = torch.tensor([40, 700])
+    ref = ou.unet_forward(p, cfg, x, t, ctx)
+    served = ("proj_in", "proj_out", "to_q", "to_k", "to_v", "to_out.0", "ff.net.0.proj")
+    try:
+        # the engine's fp8 set: K in {320, 640} linears of the transformer blocks (attn2.to_k / to_v have K = the context width)
+        ou.FP8_LINEARS = lambda name, K: K in (320, 640) and name.endswith(served)
+        ref8 = ou.unet_forward(p, cfg, x, t, ctx)
+    finally:
+        ou.FP8_LINEARS = None
+    lib = L.lib()
+    net8 = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, fp8="all")
+    net8.load_state_dict(p)
+    net8(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda())
+    lib.mrisr_prof_reset(); lib.mrisr_prof_enable(1)
+    out8 = net8(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+    torch.cuda.synchronize(); lib.mrisr_prof_enable(0)
+    buf = C.create_string_buffer(1 << 20)
+    n = lib.mrisr_prof_report(buf, len(buf))
+    classes = json.loads(buf.value[:n].decode())
+    lib.mrisr_prof_reset()
+    assert any(k.startswith("gemm_fp8_rp320") for k in classes) and any(k.startswith("gemm_fp8_rp640") for k in classes), sorted(classes)
+    net16 = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
+    net16.load_state_dict(p)
+    out16 = net16(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+    e8, e16, e8x = rel(out8, ref8), rel(out16, ref), rel(out8, ref)
+    print(f"fp8 engine vs fake-quant oracle {e8:.4e}; bf16 engine vs oracle {e16:.4e}; fp8 engine vs unquantised oracle {e8x:.4e}")
+    # e4m3 carries 3 mantissa bits: ~5 % through the whole network; the two fp8 computations round different bf16 / f32 inputs, so
+    # their quantisation noise is only partly shared - the bound is the fp8 noise level, the layout / scale check is the op test above
+    assert e16 < 5e-2 and e8 < 8e-2 and e8x < 1.0e-1
+    with pytest.raises(ValueError):
+        mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", fp8=True)
+
+
 def test_unet_with_specialised_kernels_preferred():
     """SD-1.5 channel widths at a tiny spatial size, bf16 + explicit LoRA: the same forward with the autotuner's choice and
     with the weight-stationary / halo kernels preferred wherever they are eligible (incl. the in-kernel LoRA

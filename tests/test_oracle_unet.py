@@ -200,3 +200,29 @@ def test_attention_matches_scaled_dot_product_attention(heads, d, nq, nk):
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
         want = lin("to_out.0", o.transpose(1, 2).reshape(2, nq, C))
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), float((got - want).abs().max())
+
+
+def test_fp8_fake_quant_is_e4m3_round_to_nearest_with_row_scales():
+    """The oracle's fake-quant (BASELINE configs[4]): exact on e4m3-representable rows, max at 448, <= 2^-4 relative error
+    elsewhere (3 mantissa bits), scale per row."""
+    grid = torch.tensor([[0.0, 1.0, 1.125, 1.25, 1.5, 1.75, 2.0, 3.5, 448.0, -448.0, 0.015625, 208.0]])
+    assert torch.equal(ou.fp8_fake_quant_rows(grid), grid)                      # amax = 448 -> scale 1: representable values survive
+    x = torch.randn(5, 320, generator=torch.Generator().manual_seed(3)) * torch.tensor([[1e-3], [1.0], [50.0], [1e4], [7.0]])
+    q = ou.fp8_fake_quant_rows(x)
+    s = x.abs().amax(-1, keepdim=True) / 448
+    assert torch.allclose(q.abs().amax(-1), x.abs().amax(-1))                   # the row maximum maps to 448 exactly
+    big = x.abs() > 16 * 2.0 ** -6 * s                                           # normal range of e4m3 after scaling
+    assert float(((q - x).abs() / x.abs())[big].max()) <= 2.0 ** -4 + 1e-6
+    # the hook: only the selected linears change, and by a bounded amount
+    p = {"l.weight": torch.randn(64, 320), "l.bias": torch.randn(64)}
+    xin = torch.randn(3, 7, 320)
+    ref = ou.linear(p, "l", xin)
+    try:
+        ou.FP8_LINEARS = lambda name, K: K == 320
+        got = ou.linear(p, "l", xin)
+        ou.FP8_LINEARS = lambda name, K: K == 640
+        assert torch.equal(ou.linear(p, "l", xin), ref)
+    finally:
+        ou.FP8_LINEARS = None
+    e = float((got - ref).norm() / ref.norm())
+    assert 1e-3 < e < 6e-2, e

@@ -20,11 +20,13 @@ cfg = mrisr.UNetConfig()
 sd = P.random_state_dict(P.unet_param_shapes(cfg), bench.SEED, dev)
 sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), bench.SEED + 3, dev))
 merged = "--lora-merged" in sys.argv
-unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, lora_fused=not merged)
+fp8 = os.environ.get("MRISR_FP8", "0") == "1"  # BASELINE configs[4]: fp8 projections
+BATCH = int(os.environ.get("MRISR_BATCH", "32"))
+unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, lora_fused=not merged, fp8=fp8)
 unet.load_state_dict(sd)
 sched = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
 sched.set_timesteps(50)
-lr_lat, ctx, noise, _hr = bench.synthetic_batch(32, dev, 0)
+lr_lat, ctx, noise, _hr = bench.synthetic_batch(BATCH, dev, 0)
 lat = (lr_lat + noise).contiguous()
 smp = mrisr.Sampler(unet, sched, kind="ddim")
 smp.set_range(0, 1)

@@ -171,6 +171,11 @@ int mrisr_adapter_train_tensor_info(const mrisr_adapter* a, int i, const char** 
 int mrisr_adapter_train_bind(mrisr_adapter* a, float* theta_dev, float* grad_dev, int init_from_model, void* stream);
 int mrisr_adapter_train_refresh(mrisr_adapter* a, void* stream);
 int mrisr_adapter_backward(mrisr_adapter* a, const mrisr_tensor* d_feats, int n_feats, void* stream);
+/* The same pass cut at level boundaries, so that the host can start the exchange of a level's finished weight gradients while
+ * the lower levels are still being differentiated: call with level = top level, ..., 0 (level 0 also
+ * differentiates conv_in).  mrisr_adapter_train_level_range: that level's contiguous range of the flat trainable vector. */
+int mrisr_adapter_backward_level(mrisr_adapter* a, const mrisr_tensor* d_feats, int n_feats, int level, void* stream);
+int mrisr_adapter_train_level_range(const mrisr_adapter* a, int level, int64_t* offset, int64_t* numel);
 
 /* ---- AutoencoderKL (SD-1.5 VAE): pixel <-> latent, once before / once after the sampling loop --------------
  * Replaces vae.encode(x).latent_dist (res_srdiff.py:49-50) and vae.decode(z).sample (res_srdiff.py:107-110); the

@@ -440,6 +440,8 @@ struct mrisr_adapter {
     float* grad = nullptr;
     Act rec_u;
     std::vector<AdRec> recs;
+    Act bwd_dcur;             // running gradient between the level-wise backward calls
+    int bwd_next_level = -1;  // next level mrisr_adapter_backward_level expects (descending)
     std::vector<ConvW*> all_convs() {
         std::vector<ConvW*> v{&conv_in};
         for (auto& b : blocks) {
@@ -549,11 +551,14 @@ struct AdRunner {
         return 0;
     }
     // d_feats: gradients w.r.t. the four feature maps (what mrisr_train_step wrote through mrisr_train_set_intrablock_grads)
-    int backward(const mrisr_tensor* d_feats, int n_feats) {
+    // Blocks k_hi .. k_lo (descending) of the backward; the running gradient lives in a.bwd_dcur between calls, so that the host
+    // can cut the pass at level boundaries and start the exchange of a level's finished weight gradients while the lower
+    // levels are still being differentiated (mrisr_adapter_backward_level).
+    int backward_blocks(const mrisr_tensor* d_feats, int n_feats, int k_hi, int k_lo, bool with_conv_in) {
         MRISR_REQUIRE(a.recorded || dry, "run the adapter forward first");
         MRISR_REQUIRE(n_feats * a.cfg.nums_rb == (int)a.blocks.size(), "one feature gradient per level");
-        Act dcur;
-        for (int k = (int)a.blocks.size() - 1; k >= 0; --k) {
+        Act dcur = a.bwd_dcur;
+        for (int k = k_hi; k >= k_lo; --k) {
             AdBlock& b = a.blocks[k];
             AdRec& r = a.recs[k];
             if ((k + 1) % a.cfg.nums_rb == 0) {
@@ -595,7 +600,23 @@ struct AdRunner {
             }
             dcur = dx;
         }
-        return conv_wgrad(a.rec_u, dcur, a.conv_in, 1);
+        a.bwd_dcur = dcur;
+        if (with_conv_in) return conv_wgrad(a.rec_u, dcur, a.conv_in, 1);
+        return 0;
+    }
+    int backward(const mrisr_tensor* d_feats, int n_feats) {
+        a.bwd_dcur = Act();
+        a.bwd_next_level = -1;
+        return backward_blocks(d_feats, n_feats, (int)a.blocks.size() - 1, 0, true);
+    }
+    // one level (nums_rb blocks) of the backward, levels in descending order; level 0 also differentiates conv_in
+    int backward_level(const mrisr_tensor* d_feats, int n_feats, int level) {
+        const int nlev = (int)a.blocks.size() / a.cfg.nums_rb;
+        MRISR_REQUIRE(level >= 0 && level < nlev, "adapter level");
+        if (level == nlev - 1) { a.bwd_dcur = Act(); a.bwd_next_level = level; }
+        MRISR_REQUIRE(a.bwd_next_level == level, "adapter backward levels must run in descending order, starting at the top level");
+        a.bwd_next_level = level - 1;
+        return backward_blocks(d_feats, n_feats, (level + 1) * a.cfg.nums_rb - 1, level * a.cfg.nums_rb, level == 0);
     }
 
     int forward(const mrisr_tensor& x, mrisr_tensor* feats, int n_feats) {
@@ -832,6 +853,30 @@ int mrisr_adapter_backward(mrisr_adapter* a, const mrisr_tensor* d_feats, int n_
     if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, false}; return r.backward(d_feats, n_feats); }
     AdRunner<bf16> r{*a, st, false};
     return r.backward(d_feats, n_feats);
+    API_END
+}
+int mrisr_adapter_backward_level(mrisr_adapter* a, const mrisr_tensor* d_feats, int n_feats, int level, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(a && d_feats && a->train_ready && a->grad, "bind the adapter's trainable vector first");
+    hipStream_t st = (hipStream_t)stream;
+    if (a->cfg.compute_dtype == MRISR_F32) { AdRunner<float> r{*a, st, false}; return r.backward_level(d_feats, n_feats, level); }
+    AdRunner<bf16> r{*a, st, false};
+    return r.backward_level(d_feats, n_feats, level);
+    API_END
+}
+int mrisr_adapter_train_level_range(const mrisr_adapter* ac, int level, int64_t* offset, int64_t* numel) {
+    API_BEGIN
+    mrisr_adapter* a = const_cast<mrisr_adapter*>(ac);
+    MRISR_REQUIRE(a && a->train_ready && offset && numel, "adapter not prepared for training");
+    const int rb = a->cfg.nums_rb, nlev = (int)a->blocks.size() / rb;
+    MRISR_REQUIRE(level >= 0 && level < nlev, "adapter level");
+    // all_convs() order = flat-vector order: conv_in, then per block (down, in_conv, block1, block2): a level is one contiguous range
+    auto first_off = [&](AdBlock& b) { return b.down ? b.down_w.offW : (b.has_in ? b.in_w.offW : b.b1.offW); };
+    const long long lo = level == 0 ? 0 : first_off(a->blocks[level * rb]);
+    const long long hi = level + 1 < nlev ? first_off(a->blocks[(level + 1) * rb]) : a->n_trainable;
+    *offset = lo;
+    *numel = hi - lo;
+    return 0;
     API_END
 }
 

@@ -59,7 +59,7 @@ EXPORTS = [
     "mrisr_adapter_destroy", "mrisr_adapter_set_param", "mrisr_adapter_finalize", "mrisr_adapter_forward",
     "mrisr_resshift_forward", "mrisr_sampler_create", "mrisr_sampler_destroy", "mrisr_sampler_run", "mrisr_sampler_set_range", "mrisr_sampler_set_clip",
     "mrisr_adapter_train_prepare", "mrisr_adapter_train_num_trainable", "mrisr_adapter_train_num_tensors",
-    "mrisr_adapter_train_tensor_info", "mrisr_adapter_train_bind", "mrisr_adapter_train_refresh", "mrisr_adapter_backward",
+    "mrisr_adapter_train_tensor_info", "mrisr_adapter_train_bind", "mrisr_adapter_train_refresh", "mrisr_adapter_backward", "mrisr_adapter_backward_level", "mrisr_adapter_train_level_range",
     "mrisr_vae_create", "mrisr_vae_destroy", "mrisr_vae_set_param", "mrisr_vae_num_params", "mrisr_vae_finalize",
     "mrisr_vae_encode", "mrisr_vae_decode",
     "mrisr_image_metrics",

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from .dist import all_reduce_sum_
+from .dist import BucketedReducer, all_reduce_sum_
 
 
 def cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int, num_cycles: float = 0.5) -> float:
@@ -107,6 +107,17 @@ class _FlatAdamW:
                                           C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                           C.c_float(self.weight_decay), C.c_int(self.step_count), L.stream_ptr()))
         self._last_sumsq = ss
+
+    def _adamw_range(self, lo: int, hi: int, world: int, lr: Optional[float], sumsq: torch.Tensor):
+        """AdamW on the slice [lo, hi) only (the sharded optimiser of ``joint_step_overlapped``); ``step_count`` is the caller's."""
+        es = 4
+        L.check(L.lib().mrisr_optim_adamw(C.c_void_p(self.theta.data_ptr() + lo * es), C.c_void_p(self.grad.data_ptr() + lo * es),
+                                          C.c_void_p(self.exp_avg.data_ptr() + lo * es), C.c_void_p(self.exp_avg_sq.data_ptr() + lo * es),
+                                          C.c_int64(hi - lo), C.c_void_p(sumsq.data_ptr()), C.c_float(1.0 / world),
+                                          C.c_float(self.max_grad_norm or 0.0), C.c_float(self.lr if lr is None else lr),
+                                          C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                          C.c_float(self.weight_decay), C.c_int(self.step_count), L.stream_ptr()))
+        self._last_sumsq = sumsq
 
     # ---- EMA of the trainable parameters (diffusers EMAModel: use_ema in the reference's training config) ----
     def ema_init(self):
@@ -310,9 +321,72 @@ class AdapterTrainer(_FlatAdamW):
         arr = L.tensor_array([L.as_tensor(f) for f in g])
         L.check(L.lib().mrisr_adapter_backward(self.adapter._h, arr, len(g), L.stream_ptr()))
 
+    # ---- the same pass, one level at a time (top level first): lets the exchange of a level's gradients overlap the rest ----
+    @property
+    def num_levels(self) -> int:
+        return len(self.adapter.channels)
+
+    def level_range(self, level: int) -> Tuple[int, int]:
+        """[lo, hi) of the flat trainable / gradient vector holding this level's convolutions (level 0: incl. conv_in)."""
+        off, n = C.c_int64(), C.c_int64()
+        L.check(L.lib().mrisr_adapter_train_level_range(self.adapter._h, int(level), C.byref(off), C.byref(n)))
+        return int(off.value), int(off.value + n.value)
+
+    def backward_level(self, feature_grads: Sequence[torch.Tensor], level: int):
+        g = [f.to(self.adapter.device).contiguous() for f in feature_grads]
+        arr = L.tensor_array([L.as_tensor(f) for f in g])
+        L.check(L.lib().mrisr_adapter_backward_level(self.adapter._h, arr, len(g), int(level), L.stream_ptr()))
+
     def optimizer_step(self, world: int = 1, lr: Optional[float] = None, sumsq: Optional[torch.Tensor] = None):
         self._adamw(world, lr, sumsq)
         L.check(L.lib().mrisr_adapter_train_refresh(self.adapter._h, L.stream_ptr()))
+
+
+def joint_step_overlapped(lora: LoRATrainer, adapter: AdapterTrainer, noisy_latents, timesteps, encoder_hidden_states, target,
+                          adapter_input, lr: Optional[float] = None, mode: str = "all_reduce"):
+    """``joint_step`` with the large-bucket exchange of SURVEY.md 8e: the adapter's 935 MB gradient vector is reduced level by
+    level (buckets in backward order: level 3 first) while the lower levels are still being differentiated, instead of one
+    all-reduce after the whole backward; ``mode="reduce_scatter"`` additionally shards the adapter's AdamW step over the ranks
+    (``BucketedReducer``).  Same arithmetic as ``joint_step``: the clip uses the global norm over both parameter sets."""
+    lora.zero_grad()
+    adapter.zero_grad()
+    feats = adapter.forward(adapter_input)
+    fg = adapter.new_feature_grads()
+    loss = lora.forward_backward(noisy_latents, timesteps, encoder_hidden_states, target, down_intrablock_additional_residuals=feats,
+                                 feature_grads=fg)
+    levels = list(range(adapter.num_levels - 1, -1, -1))
+    red = BucketedReducer(adapter.grad, [adapter.level_range(l) for l in levels], adapter.group, mode)
+    # the LoRA bucket (3.19 MB) is final already: its collective goes first and hides behind the adapter's backward too
+    lred = BucketedReducer(lora.grad, [(0, lora.grad.numel())], lora.group, "all_reduce")
+    lred.reduce(0)
+    for i, l in enumerate(levels):
+        adapter.backward_level(fg, l)
+        red.reduce(i)
+    world = red.wait()
+    lred.wait()
+    if mode == "all_reduce" or world == 1:
+        total = lora.sumsq().clone() + adapter.sumsq()
+        lora.optimizer_step(world, lr, sumsq=total)
+        adapter.optimizer_step(world, lr, sumsq=total)
+        return loss
+    # reduce_scatter: this rank holds the summed gradient of its shards only - its share of the squared norm, one scalar
+    # all-reduce, then AdamW on the shards and an all-gather of the updated parameters
+    import torch.distributed as dist
+    part = torch.zeros(1, dtype=torch.float32, device=adapter.grad.device)
+    for i in range(len(levels)):
+        lo, hi = red.shard(i)
+        part += adapter.grad[lo:hi].double().pow(2).sum().float()
+    dist.all_reduce(part, group=adapter.group)
+    total = lora.sumsq().clone() + part
+    lora.optimizer_step(world, lr, sumsq=total)
+    adapter.step_count += 1
+    for i in range(len(levels)):
+        lo, hi = red.shard(i)
+        if hi > lo:
+            adapter._adamw_range(lo, hi, world, lr, total)
+    red.all_gather_params(adapter.theta)
+    L.check(L.lib().mrisr_adapter_train_refresh(adapter.adapter._h, L.stream_ptr()))
+    return loss
 
 
 def joint_step(lora: LoRATrainer, adapter: AdapterTrainer, noisy_latents, timesteps, encoder_hidden_states, target, adapter_input,

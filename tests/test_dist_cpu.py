@@ -179,3 +179,89 @@ def test_lora_checkpoint_key_forms_and_ema_schedule():
     assert d(5, update_after_step=10) == 0.0 and d(12, update_after_step=10) == 2 / 11
     assert abs(d(11, use_ema_warmup=True, inv_gamma=1.0, power=2 / 3) - (1 - 11 ** (-2 / 3))) < 1e-15
     assert d(3, min_decay=0.5) == 0.5
+
+
+def _bucket_worker(rank, world, port, out):
+    """SURVEY.md 8e large-bucket exchange: the flat gradient vector reduced bucket by bucket in backward order (async) equals
+    ONE flat all-reduce; in reduce_scatter mode a rank owns the summed slice of every bucket, updates only those parameters,
+    and the all-gather of the updated slices reproduces the full update on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mri-diffusion-superresolution_amd"))
+    from mrisr import dist as md
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000 + 37                                                      # ragged on purpose
+    ranges = [(700, n), (300, 700), (0, 300)]                          # backward order: the top of the vector first
+    g = torch.Generator().manual_seed(1234 + rank)
+    grad = torch.randn(n, generator=g)
+    flat = grad.clone()
+    md.all_reduce_sum_(flat)                                           # the round-1 exchange: one flat all-reduce
+    res = {}
+    buck = grad.clone()
+    red = md.BucketedReducer(buck, ranges, mode="all_reduce")
+    for i in range(len(ranges)):
+        red.reduce(i)
+    res["world"] = red.wait()
+    res["bucketed_equals_flat"] = bool(torch.equal(buck, flat))
+    # sharded optimiser: theta' = theta - 0.1 * mean gradient, computed only on this rank's shards, then all-gathered
+    theta0 = torch.arange(n, dtype=torch.float32) / n
+    sh = grad.clone()
+    red2 = md.BucketedReducer(sh, ranges, mode="reduce_scatter")
+    for i in range(len(ranges)):
+        red2.reduce(i)
+    red2.wait()
+    theta = theta0.clone()
+    own = 0
+    for i in range(len(ranges)):
+        lo, hi = red2.shard(i)
+        theta[lo:hi] -= 0.1 * sh[lo:hi] / world
+        own += hi - lo
+    red2.all_gather_params(theta)
+    want = theta0 - 0.1 * flat / world
+    res["sharded_update_ok"] = bool(torch.allclose(theta, want, rtol=0, atol=1e-7))
+    res["own"] = own
+    shards = [None] * world
+    dist.all_gather_object(shards, [red2.shard(i) for i in range(len(ranges))])
+    if rank == 0:
+        res["shards"] = shards
+        out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_exchange_equals_flat_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["world"] == 2 and res["bucketed_equals_flat"] and res["sharded_update_ok"]
+    # the two ranks' shards tile every bucket
+    for i, (lo, hi) in enumerate([(700, 1037), (300, 700), (0, 300)]):
+        a, b = res["shards"][0][i], res["shards"][1][i]
+        assert a[0] == lo and a[1] == b[0] and b[1] == hi and abs((a[1] - a[0]) - (b[1] - b[0])) <= 1
+    assert abs(res["own"] - 1037 / 2) <= 2
+
+
+def test_bucketed_reducer_validates_and_is_identity_without_group():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mri-diffusion-superresolution_amd"))
+    from mrisr import dist as md
+    v = torch.arange(10, dtype=torch.float32)
+    r = md.BucketedReducer(v, [(6, 10), (0, 6)])
+    r.reduce(0); r.reduce(1)
+    assert r.wait() == 1 and torch.equal(v, torch.arange(10, dtype=torch.float32)) and r.shard(0) == (6, 10)
+    r.all_gather_params(v)
+    with pytest.raises(ValueError):
+        md.BucketedReducer(v, [(0, 4), (5, 10)])   # gap
+    with pytest.raises(ValueError):
+        md.BucketedReducer(v, [(0, 10)], mode="ring")

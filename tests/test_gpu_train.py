@@ -336,6 +336,51 @@ def test_joint_lora_adapter_step_matches_torch(tiny):
         assert rel(f, r) < 1e-3
 
 
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_overlapped_joint_step_equals_joint_step(tiny, mode):
+    """the config-3 step with the adapter's backward cut at level boundaries and each level's gradient bucket
+    handed to the exchange as soon as it is final (mrisr.joint_step_overlapped) gives the same parameters as the round-1 step
+    (whole backward, then one all-reduce) - without a process group and through a single-rank RCCL group, both exchange modes;
+    level ranges tile the flat vector and the level-wise backward refuses a wrong order."""
+    import socket
+    import torch.distributed as dist
+    import mrisr
+    cfg, up, lora = tiny
+    acfg, ap = _adapter_setup(seed=151)
+    B, h = 2, 8
+
+    def run(step_fn, steps=2):
+        net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4, lora_fused=True)
+        net.load_state_dict({**up, **lora})
+        ad = mrisr.Adapter_XL(channels=acfg.channels, nums_rb=acfg.nums_rb, cin=acfg.cin, ksize=acfg.ksize, compute_dtype="f32")
+        ad.load_state_dict(ap)
+        kw = dict(lr=1e-3, max_grad_norm=1.0)
+        ltr, atr = mrisr.LoRATrainer(net, **kw), mrisr.AdapterTrainer(ad, **kw)
+        losses = []
+        for s in range(steps):
+            x, t, ctx, tgt = make_batch(cfg, B, h, 180 + s, L=16)
+            cond = torch.randn((B, 3, 8 * h, 8 * h), generator=torch.Generator().manual_seed(190 + s))
+            losses.append(float(step_fn(ltr, atr, x.cuda(), t.cuda(), ctx.cuda(), (50.0 * tgt).cuda(), cond.cuda())))
+        return ltr, atr, losses
+
+    l0, a0, loss0 = run(mrisr.joint_step)
+    # level ranges: contiguous, descending levels tile [0, n)
+    rng = [a0.level_range(l) for l in range(a0.num_levels)]
+    assert rng[0][0] == 0 and rng[-1][1] == a0.num_trainable and all(rng[i][1] == rng[i + 1][0] for i in range(len(rng) - 1))
+    with pytest.raises(mrisr.MrisrError, match="descending"):
+        a0.forward(torch.zeros(B, 3, 8 * h, 8 * h).cuda())
+        a0.backward_level(a0.new_feature_grads(), 0)
+    l1, a1, loss1 = run(lambda *a: mrisr.joint_step_overlapped(*a, mode=mode))
+    assert loss1 == loss0 and rel(l1.theta, l0.theta) < 1e-6 and rel(a1.theta, a0.theta) < 1e-6
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        l2, a2, loss2 = run(lambda *a: mrisr.joint_step_overlapped(*a, mode=mode))
+    finally:
+        dist.destroy_process_group()
+    assert rel(l2.theta, l0.theta) < 1e-5 and rel(a2.theta, a0.theta) < 1e-5 and abs(loss2[-1] - loss0[-1]) < 1e-5 * abs(loss0[-1])
+
+
 def test_ema_and_checkpoint_roundtrip(tiny, tmp_path):
     """EMA of the adapters (diffusers EMAModel.step) and checkpoint interchange: parameters as safetensors under their peft
     keys, optimiser moments alongside; a restored trainer continues bit-identically."""

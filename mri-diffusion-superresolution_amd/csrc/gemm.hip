@@ -1301,8 +1301,34 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     };
 
     // ---- the panel rows: registers, MFMA second-operand layout (row = fr of fragment j, k = 32 kk + 8 fg ..) ----
+    // A_VIA_LDS (K = 320): the wave's 32 rows (20 KB) come in as whole 1-KiB LDS-DMA pieces into a wave-private region of the
+    // (still empty) weight buffers and are then read out in fragment layout.  Loading the fragments straight from global
+    // memory fetches every 128-byte line of a row twice as two 64-byte halves (k-steps 2t and 2t + 1): the load phase ran at
+    // 3.8 TB/s of L2 traffic for 21 MB of rows (tools/probes/rp_probe.sh, flags 448).
+    constexpr bool A_VIA_LDS = KS == 10 && 4 * 32 * K * 2 <= 2 * CHUNK + (FP8 ? 40960 : 0);
     bf16x8 af[MF][KS];
-    {
+    if constexpr (A_VIA_LDS) {
+        constexpr int ACPR = K / 8;                       // 16-byte chunks per row
+        constexpr int APIECES = 32 * ACPR / 64;           // pieces per wave
+        char* areg = smem + wave * (32 * K * 2);
+#pragma unroll
+        for (int p = 0; p < APIECES; ++p) {
+            const int L = p * 64 + lane;
+            const int row = L / ACPR, cs = L - row * ACPR;
+            const int c = cs ^ (row & 7);
+            const int m = m0 + wave * 32 + row;
+            const unsigned vo = m < g.M ? (unsigned)(((size_t)m * g.lda0 + c * 8) * 2) : BL_OOB;
+            bl16(ra, areg + p * 1024, vo, 0u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own pieces (the region is wave-private: no barrier)
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                af[j][kk] = *reinterpret_cast<const bf16x8*>(areg + (j * 16 + fr) * (K * 2) + (((kk * 4 + fg) ^ (fr & 7)) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave has its rows in registers: the buffers may receive weights
+    } else {
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
             const int m = m0 + wave * 32 + j * 16 + fr;
@@ -1971,7 +1997,7 @@ int gemm_rp_tile(const GemmArgs& g) {
 template <int KS, int NF, bool FP8>
 static int launch_rp(const GemmArgs& g, hipStream_t st) {
     constexpr int K = KS * 32, BN = NF * 16;
-    constexpr int smem = 2 * BN * K * (FP8 ? 1 : 2);
+    constexpr int smem = (FP8 && KS == 10) ? 81920 : 2 * BN * K * (FP8 ? 1 : 2);  // (fp8, K = 320: room for the bf16 row panel on its way in)
     constexpr int tile_id = FP8 ? (KS == 10 ? 62 : 63) : (KS == 10 ? 60 : 61);
     MRISR_REQUIRE(rp_ok(g, tile_id), "row-panel kernel: plain un-split bf16 row GEMM with K = 32*KS (fp8: packed weights + scales)");
     static bool attr = false;

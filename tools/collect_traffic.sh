@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
 # the shipped tile table (what bench.py uses), copied so that a missing signature would be appended to the copy only
-cp $R/profiles/r01_tune_cache.tsv $R/gpurun_out/tune_cache.tsv
+cp $R/profiles/r02_tune_cache.tsv $R/gpurun_out/tune_cache.tsv
 export MRISR_TUNE_CACHE=$R/gpurun_out/tune_cache.tsv
 # fill the autotune table first so that the profiled runs contain no tuning launches
 python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --ddim-steps 2 > $R/gpurun_out/traffic_warm.log 2>&1
@@ -21,6 +21,8 @@ def cls(name):
     if m: return f"gemm_bf16_bl{m.group(1)}x{m.group(2)}"
     m = re.search(r"gemm_halo_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"gemm_halo_kernel<(\d+), (\d+),", name)
     if m: return f"gemm_bf16_halo{m.group(1)}x{m.group(2)}"
+    m = re.search(r"gemm_rp_kernelILi(\d+)ELi(\d+)ELb[01]ELi[01]ELb([01])E", name) or re.search(r"gemm_rp_kernel<(\d+), (\d+), (?:true|false), [01], (true|false)>", name)
+    if m: return f"gemm_{'fp8' if m.group(3) in ('1', 'true') else 'bf16'}_rp{int(m.group(1)) * 32}x{int(m.group(2)) * 16}"
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", name)
     if m: return f"gemm_{'bf16' if m.group(1) != 'f' else 'f32'}_{m.group(2)}x{m.group(3)}"
     for k, v in (("attn_fwd", "flash_attention"), ("gn_stats", "groupnorm_stats"), ("gn_apply", "groupnorm_apply"), ("layernorm", "layernorm"),

@@ -1251,16 +1251,20 @@ __device__ __forceinline__ rp_f8x8 rp_quant8(const bf16x8& x, float inv_scale) {
     return (rp_f8x8)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-template <int KS, int NF, bool LORA, int PRO, bool FP8>
-__global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
+// NW: waves per workgroup = 32-row groups per panel.  4 (128-row panels, 2 workgroups = 8 waves per CU) or 2 (64-row panels: the
+// two co-resident workgroups put ONE wave on each SIMD, which may then use the whole 512-register file - K = 640 rows (160
+// registers of fragments per lane) fit without spilling, and a 64 x 640 panel is 80 KB = the weight buffers, so it can come in
+// through LDS as whole pieces too).
+template <int KS, int NF, bool LORA, int PRO, bool FP8, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const GemmArgs g) {
     typedef bf16 T;
-    constexpr int K = KS * 32, BN = NF * 16, BM = 128, MF = 2;
+    constexpr int K = KS * 32, BN = NF * 16, BM = 32 * NW, MF = 2;
     constexpr int EW = FP8 ? 1 : 2;             // bytes per weight element
     constexpr int CPR = KS * 4 / (FP8 ? 2 : 1); // 16-byte chunks per weight row
     constexpr int CHUNK = BN * K * EW;          // bytes of one weight chunk in LDS
     constexpr int SWZ = FP8 ? 3 : 7;            // 16-byte chunk swizzle: c ^ (f(row) & SWZ); fp8 rows are 320 / 640 B: f = row >> 2
     constexpr int PIECES = BN * CPR / 64;       // 1-KiB LDS-DMA pieces per chunk
-    constexpr int PPW = (PIECES + 3) / 4;       // pieces per wave
+    constexpr int PPW = PIECES / NW;            // pieces per wave
     static_assert((BN * CPR) % 64 == 0, "whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1282,12 +1286,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     auto swz = [](int row) { return FP8 ? ((row >> 2) & 3) : (row & 7); };
 
     // ---- weight chunk DMA geometry: LDS position L (16-byte units) = row * CPR + (c ^ swz(row)) ----
-    static_assert(PIECES % 4 == 0, "every wave issues the same number of DMA pieces (no control flow around them: the compiler's\n"
+    static_assert(PIECES % NW == 0, "every wave issues the same number of DMA pieces (no control flow around them: the compiler's\n"
                                    "wait-count model turns conditional VMEM issue into vmcnt(0) drains)");
     unsigned wvo[PPW];
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
-        const int L = (p * 4 + wave) * 64 + lane;
+        const int L = (p * NW + wave) * 64 + lane;
         const int row = L / CPR, cs = L - row * CPR;
         const int c = cs ^ swz(row);
         wvo[p] = (unsigned)(row * K * EW + c * 16);
@@ -1297,7 +1301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
         char* sb = smem + buf * CHUNK;
         const unsigned base = live ? (unsigned)chunk * (unsigned)CHUNK : 0xC0000000u;  // rows past N also lie beyond num_records
 #pragma unroll
-        for (int p = 0; p < PPW; ++p) bl16(rw, sb + (p * 4 + wave) * 1024, wvo[p], base);
+        for (int p = 0; p < PPW; ++p) bl16(rw, sb + (p * NW + wave) * 1024, wvo[p], base);
     };
 
     // ---- the panel rows: registers, MFMA second-operand layout (row = fr of fragment j, k = 32 kk + 8 fg ..) ----
@@ -1305,7 +1309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     // (still empty) weight buffers and are then read out in fragment layout.  Loading the fragments straight from global
     // memory fetches every 128-byte line of a row twice as two 64-byte halves (k-steps 2t and 2t + 1): the load phase ran at
     // 3.8 TB/s of L2 traffic for 21 MB of rows (tools/probes/rp_probe.sh, flags 448).
-    constexpr bool A_VIA_LDS = KS == 10 && 4 * 32 * K * 2 <= 2 * CHUNK + (FP8 ? 40960 : 0);
+    constexpr bool A_VIA_LDS = NW * 32 * K * 2 <= (FP8 && KS == 10 ? 81920 : 2 * CHUNK);
     bf16x8 af[MF][KS];
     if constexpr (A_VIA_LDS) {
         constexpr int ACPR = K / 8;                       // 16-byte chunks per row
@@ -1341,8 +1345,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     if (LORA) {  // the adapters' A rows (R <= 16) borrow the front of buffer 1 until chunk c_beg + 1 is staged
         constexpr int LPIECES = 16 * CPR / 64;
 #pragma unroll
-        for (int p = 0; p < (LPIECES + 3) / 4; ++p) {
-            const int piece = p * 4 + wave;
+        for (int p = 0; p < (LPIECES + NW - 1) / NW; ++p) {
+            const int piece = p * NW + wave;
             const int L = piece * 64 + lane;
             const int row = L / CPR, cs = L - row * CPR;
             const int c = cs ^ swz(row);
@@ -1470,8 +1474,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_kernel(const GemmArgs g) {
     constexpr int OPITCH = BN + 8;      // wave-private row tile [32][OPITCH]
     constexpr int TPITCH = 32 + 8;      // wave-private transposed tile [BN][TPITCH] (V^T)
     constexpr int GP = BN / 2 + 8;      // GEGLU tile [32][GP]
-    constexpr int WREG = CHUNK / 4;     // bytes of a wave's staging region inside the chunk's own (consumed) weight buffer
-    static_assert(32 * OPITCH * 2 <= WREG && BN * TPITCH * 2 <= WREG && 4 * WREG <= CHUNK, "staging regions");
+    constexpr int WREG = CHUNK / NW;     // bytes of a wave's staging region inside the chunk's own (consumed) weight buffer
+    static_assert(32 * OPITCH * 2 <= WREG && BN * TPITCH * 2 <= WREG && NW * WREG <= CHUNK, "staging regions");
     const int wm0 = wave * 32;
     const bool full_m = m0 + BM <= g.M;
     const bool heads = g.out_mode == OUT_HEADS;
@@ -1944,18 +1948,21 @@ static int launch_ws(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
-// row-panel configurations: id -> <KS, NF, FP8>   (K = 32*KS; weight chunks of 16*NF output columns x K: 40 KB bf16, 20 / 40 KB fp8)
-#define RP_CFGS(X)        \
-    X(60, 10, 4, false)   \
-    X(61, 20, 2, false)   \
-    X(62, 10, 4, true)    \
-    X(63, 20, 4, true)
+// row-panel configurations: id -> <KS, NF, FP8, NW>   (K = 32*KS; weight chunks of 16*NF output columns x K: 40 KB bf16, 20 / 40 KB
+// fp8; NW waves = 32*NW-row panels)
+#define RP_CFGS(X)           \
+    X(60, 10, 4, false, 4)   \
+    X(64, 20, 2, false, 2)   \
+    X(61, 20, 2, false, 4)   \
+    X(62, 10, 4, true, 4)    \
+    X(63, 20, 4, true, 2)    \
+    X(65, 10, 4, false, 2)
 
-static void rp_dims(int tile, int* ks, int* nf, bool* fp8) {
+static void rp_dims(int tile, int* ks, int* nf, bool* fp8, int* nw = nullptr) {
     *ks = *nf = 0;
     *fp8 = false;
     switch (tile) {
-#define X(id, k, n, f) case id: *ks = k; *nf = n; *fp8 = f; break;
+#define X(id, k, n, f, w) case id: *ks = k; *nf = n; *fp8 = f; if (nw) *nw = w; break;
         RP_CFGS(X)
 #undef X
     }
@@ -1985,34 +1992,38 @@ static bool rp_ok(const GemmArgs& g, int tile) {
     if (g.lora_a && (g.lora_r != 4 || g.lora_R > 16 || !g.lora_b || g.act == ACT_GEGLU)) return false;
     return (long long)g.M * g.lda0 * 2 < 0x7FFFFFFFll && (long long)g.N * g.K * 2 < 0x7FFFFFFFll;
 }
-// the row-panel configuration for this K (0: none); fp8 operands (g.w8) select the fp8 configurations
+// the row-panel configuration for this K when the caller must have one (LayerNorm prologue, fp8 operands; 0: none).  bf16,
+// K = 640: the 4-wave form wins on wide outputs (N = 1920: 33 vs 36 us, N = 5120: 62 vs 83 us at M = 8192) although it spills a
+// few registers, the 2-wave form on N = 640 (16.3 vs 20.0 us): tools/probes/rp_probe3.sh
 int gemm_rp_tile(const GemmArgs& g) {
     static const int env = [] { const char* e = getenv("MRISR_RP"); return e ? atoi(e) : 1; }();
     if (!env) return 0;
-#define X(id, k, n, f) if (g.K == 32 * k && rp_ok(g, id)) return id;
-    RP_CFGS(X)
-#undef X
+    if (g.w8) return g.K == 320 ? (rp_ok(g, 62) ? 62 : 0) : (rp_ok(g, 63) ? 63 : 0);
+    if (g.K == 320) return rp_ok(g, 60) ? 60 : 0;
+    if (g.K == 640) {
+        const int first = g.N > 640 ? 61 : 64, second = g.N > 640 ? 64 : 61;
+        return rp_ok(g, first) ? first : (rp_ok(g, second) ? second : 0);
+    }
     return 0;
 }
-template <int KS, int NF, bool FP8>
-static int launch_rp(const GemmArgs& g, hipStream_t st) {
-    constexpr int K = KS * 32, BN = NF * 16;
+template <int KS, int NF, bool FP8, int NW>
+static int launch_rp(int tile_id, const GemmArgs& g, hipStream_t st) {
+    constexpr int K = KS * 32, BN = NF * 16, BM = 32 * NW;
     constexpr int smem = (FP8 && KS == 10) ? 81920 : 2 * BN * K * (FP8 ? 1 : 2);  // (fp8, K = 320: room for the bf16 row panel on its way in)
-    constexpr int tile_id = FP8 ? (KS == 10 ? 62 : 63) : (KS == 10 ? 60 : 61);
     MRISR_REQUIRE(rp_ok(g, tile_id), "row-panel kernel: plain un-split bf16 row GEMM with K = 32*KS (fp8: packed weights + scales)");
     static bool attr = false;
     if (!attr) {
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 0, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 1, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 0, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 1, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 0, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, false, 1, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 0, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rp_kernel<KS, NF, true, 1, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
-    const int panels = (g.M + 127) / 128, nchunks = (g.N + BN - 1) / BN;
+    const int panels = (g.M + BM - 1) / BM, nchunks = (g.N + BN - 1) / BN;
     static const int ys_env = [] { const char* e = getenv("MRISR_RP_YSPLIT"); return e ? atoi(e) : 0; }();
     int ysplit = ys_env > 0 ? ys_env : (512 + panels / 2) / panels;  // ~2 workgroups per CU
     ysplit = std::max(1, std::min(ysplit, nchunks));
-    static const std::string base_name = std::string(FP8 ? "gemm_fp8_rp" : "gemm_bf16_rp") + std::to_string(K) + "x" + std::to_string(BN);
+    static const std::string base_name = std::string(FP8 ? "gemm_fp8_rp" : "gemm_bf16_rp") + std::to_string(K) + "x" + std::to_string(BN) + (NW == 2 ? "w2" : "");
     std::string pname = base_name;
     if (prof_enabled() && prof_shapes()) {
         char buf[160];
@@ -2033,11 +2044,11 @@ static int launch_rp(const GemmArgs& g, hipStream_t st) {
     }
     if (g.ln_gamma) {
         MRISR_REQUIRE(g.ln_beta, "LayerNorm prologue: gamma and beta");
-        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 1, FP8>), grid, dim3(256), smem, st, g);
-        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 1, FP8>), grid, dim3(256), smem, st, g);
+        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 1, FP8, NW>), grid, dim3(64 * NW), smem, st, g);
+        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 1, FP8, NW>), grid, dim3(64 * NW), smem, st, g);
     } else {
-        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 0, FP8>), grid, dim3(256), smem, st, g);
-        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 0, FP8>), grid, dim3(256), smem, st, g);
+        if (lora) hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, true, 0, FP8, NW>), grid, dim3(64 * NW), smem, st, g);
+        else hipLaunchKernelGGL((gemm_rp_kernel<KS, NF, false, 0, FP8, NW>), grid, dim3(64 * NW), smem, st, g);
     }
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -2189,7 +2200,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
     // 50-52 (weight-stationary short-K kernels) are NOT candidates: correct, but 30-60 % slower than the tiled kernels on
     // every shape they fit (profiles/r01b_ws_sweep.log: one A fragment per wave makes them LDS-read bound); kept for the record
-    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45, 60, 61};  // (62, 63: fp8 operands, chosen by the launch, not the tuner)  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
+    static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45, 60, 61, 64, 65};  // (62, 63: fp8 operands, chosen by the launch, not the tuner)  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
         {   // debugging aid: MRISR_TUNE_SKIP="41,43" removes candidates
@@ -2330,7 +2341,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 #define X(id, ks, nb) case id: rc = launch_ws<ks, nb>(g, st); break;
         WS_CFGS(X)
 #undef X
-#define X(id, ks, nf, f8) case id: rc = launch_rp<ks, nf, f8>(g, st); break;
+#define X(id, ks, nf, f8, nw) case id: rc = launch_rp<ks, nf, f8, nw>(id, g, st); break;
         RP_CFGS(X)
 #undef X
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;

@@ -21,10 +21,11 @@ def cls(name):
     if m: return f"gemm_bf16_bl{m.group(1)}x{m.group(2)}"
     m = re.search(r"gemm_halo_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"gemm_halo_kernel<(\d+), (\d+),", name)
     if m: return f"gemm_bf16_halo{m.group(1)}x{m.group(2)}"
-    m = re.search(r"gemm_rp_kernelILi(\d+)ELi(\d+)ELb[01]ELi[01]ELb([01])E", name) or re.search(r"gemm_rp_kernel<(\d+), (\d+), (?:true|false), [01], (true|false)>", name)
+    m = re.search(r"gemm_rp_kernelILi(\d+)ELi(\d+)ELb[01]ELi[01]ELb([01])E", name) or re.search(r"gemm_rp_kernel<(\d+), (\d+), (?:true|false), [01], (true|false), \d+>", name)
     if m: return f"gemm_{'fp8' if m.group(3) in ('1', 'true') else 'bf16'}_rp{int(m.group(1)) * 32}x{int(m.group(2)) * 16}"
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", name)
     if m: return f"gemm_{'bf16' if m.group(1) != 'f' else 'f32'}_{m.group(2)}x{m.group(3)}"
+    if "gn_fused" in name: return "groupnorm_fused"
     for k, v in (("attn_fwd", "flash_attention"), ("gn_stats", "groupnorm_stats"), ("gn_apply", "groupnorm_apply"), ("layernorm", "layernorm"),
                  ("splitk_reduce", "splitk_reduce"), ("lora_down", "lora_down"), ("small_conv", "small_conv"), ("gemv_rows", "time_embed_gemv")):
         if k in name: return v

@@ -564,7 +564,12 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 // a fully out-of-range LDS-DMA instruction retires out of order, so a counted wait is only safe without padding rows.
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool LORA>
 __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  // 2 waves / SIMD: two workgroups per CU hide each other's loads
-    static_assert(NSTAGE == 2, "double buffer only (see the note above)");
+    // NSTAGE 3 / 4 (round 2): a ring with a COUNTED vmcnt - NSTAGE - 1 K tiles in flight per workgroup.  For the shapes whose
+    // whole grid is resident at once (level-2 linears: M = 2,048, 640 workgroups of 64 x 64 = 2.5 per CU) the run time is the
+    // length of ONE workgroup's chain of K-step latencies (20 steps x ~1 us); nothing else can overlap it, so the chain itself
+    // has to be pipelined.  The launcher admits these configurations only for plain GEMMs that tile exactly (every DMA
+    // instruction in range: a fully out-of-range LDS-DMA instruction retires out of order and would satisfy the count early).
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2 (drain per tile), 3 or 4 (counted ring)");
     typedef bf16 T;
     constexpr int BK = 64;
     constexpr int A_IT = BM / 32, W_IT = BN / 32;
@@ -654,10 +659,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
     // adapter rows (LORA): waves 0 and 1 each bring 8 of the 16 rows of every K tile
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(LORA ? g.lora_a : (const void*)wp, LORA ? (unsigned)((long long)g.lora_R * g.K * 2) : 0u);
     unsigned lvo = BL_OOB;
-    if (LORA && wave < 2) {
-        const int row = wave * 8 + (lane >> 3);
+    if (LORA && (wave < 2 || NSTAGE > 2)) {  // ring variants: waves 2, 3 re-issue the two pieces (same bytes, same LDS addresses) so
+                                             // that every wave's vmcnt sees the same number of DMA instructions per stage
+        const int row = (wave & 1) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
         if (row < g.lora_R) lvo = (unsigned)(((size_t)row * g.K + c * 8) * 2);
+        // ring variants: no out-of-range lanes (a FULLY out-of-range piece - rows 8..15 at R <= 8 - would retire out of order and
+        // break the counted wait); the rows >= R then carry a copy of row R - 1, whose z columns only ever meet zero B entries
+        else if (NSTAGE > 2) lvo = (unsigned)(((size_t)(g.lora_R - 1) * g.K + c * 8) * 2);
     }
 
     const int nkt = g.K / BK;
@@ -679,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
         const unsigned k0b = (unsigned)kt * BK * 2;
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, wvo[it], k0b);
-        if (LORA && wave < 2) bl16(rl, sb + (BM + BN) * 128 + wave * 64 * 16, lvo, k0b);
+        if (LORA && (wave < 2 || NSTAGE > 2)) bl16(rl, sb + (BM + BN) * 128 + (wave & 1) * 64 * 16, lvo, k0b);
         if (!g.conv) {
             const bool second = kt * BK >= g.c0;
             if (!second) {
@@ -776,18 +785,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
         }
     };
 
-    if (kt_beg < kt_end) {
-        stage(kt_beg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kt_beg; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
-            compute(cur);
+    if constexpr (NSTAGE == 2) {
+        if (kt_beg < kt_end) {
+            stage(kt_beg, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            cur ^= 1;
+            int cur = 0;
+            for (int kt = kt_beg; kt < kt_end; ++kt) {
+                if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+                compute(cur);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
         }
+    } else {
+        constexpr int PER = A_IT + W_IT + (LORA ? 1 : 0);  // DMA instructions per lane and stage (uniform over the waves)
+        static_assert(PER * (NSTAGE - 2) <= 63, "vmcnt range");
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (kt_beg + s < kt_end) stage(kt_beg + s, s);
+        int slot = 0;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            // tile kt must have landed; up to NSTAGE - 2 younger tiles stay in flight
+            const int younger = min(NSTAGE - 2, kt_end - 1 - kt);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * 2) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile kt visible to every wave; every wave has finished tile kt - 1 (its slot is refilled below)
+            if (kt + NSTAGE - 1 < kt_end) stage(kt + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
+            compute(slot);
+            slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        }
+        __syncthreads();  // the epilogue reuses the stage buffers
     }
 
     float* zlds = reinterpret_cast<float*>(smem);  // [BM][16] f32: z rows of this tile (the stages are drained)
@@ -1772,6 +1802,9 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     constexpr int smem = NSTAGE * (BM + BN) * 128;
     constexpr int smem_l = NSTAGE * ((BM + BN) * 128 + 16 * 128);
     if (prepare_bl<BM, BN, WGM, WGN, NSTAGE>()) return 1;
+    if (NSTAGE > 2)
+        MRISR_REQUIRE(!g.conv && !g.c1 && !g.a1 && g.batch == 1 && g.splitk == 1 && g.M % BM == 0 && g.N % BN == 0,
+                      "counted-ring GEMM: plain single-source un-split GEMM that tiles exactly");
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     const_cast<GemmArgs&>(g).group_m = auto_group_m(ntm, ntn, BM, BN);
     dim3 grid(ntn * ntm, g.splitk, g.batch);
@@ -1815,7 +1848,12 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     X(28, 128, 192, 2, 2, 2)   \
     X(29, 192, 128, 2, 2, 2)   \
     X(30, 160, 128, 2, 2, 2)   \
-    X(31, 96, 160, 2, 2, 2)
+    X(31, 96, 160, 2, 2, 2)    \
+    X(32, 64, 64, 2, 2, 4)     \
+    X(33, 64, 64, 2, 2, 3)     \
+    X(34, 64, 128, 2, 2, 3)    \
+    X(35, 128, 64, 2, 2, 3)    \
+    X(36, 128, 128, 2, 2, 3)
 
 static int prepare_bls() {
 #define X(id, bm, bn, wm, wn, ns) if (prepare_bl<bm, bn, wm, wn, ns>()) return 1;
@@ -2054,6 +2092,19 @@ static int launch_rp(int tile_id, const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// counted-ring configurations (NSTAGE > 2): plain single-source GEMMs that tile exactly (every DMA instruction fully in range)
+static bool ring_ok(const GemmArgs& g, int tile) {
+    int bm = 0, bn = 0, ns = 0;
+    switch (tile) {
+#define X(id, m_, n_, wm, wn, st) case id: bm = m_; bn = n_; ns = st; break;
+        BL_CFGS(X)
+#undef X
+    }
+    if (ns <= 2) return true;
+    if (g.conv || g.c1 || g.a1 || g.batch != 1) return false;
+    return g.M % bm == 0 && g.N % bn == 0 && g.K >= 64 * ns;
+}
+
 // buffer descriptors address at most 2^31 bytes per operand
 static bool bl_ok(const GemmArgs& g) {
     const long long a_rows = g.conv ? (long long)g.B * g.Hin * g.Win : (long long)g.M;
@@ -2200,6 +2251,10 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     MRISR_CHECK_HIP(hipEventRecord(t0, nullptr));
     // 50-52 (weight-stationary short-K kernels) are NOT candidates: correct, but 30-60 % slower than the tiled kernels on
     // every shape they fit (profiles/r01b_ws_sweep.log: one A fragment per wave makes them LDS-read bound); kept for the record
+    // (32-36, the counted-ring variants, are NOT candidates: on the shapes they were built for - level-2 linears, M = 2,048 - they
+    // tie or lose: 64 x 64: 16.7 us with 2 stages, 17.1 with 3, 24.4 with 4 (LDS then admits 2 workgroups per CU instead of 5);
+    // these GEMMs move 210 MB through LDS in 16.7 us = 12.6 TB/s, i.e. they sit at the L2 -> LDS bandwidth, not on a latency chain:
+    // profiles/r02i_ring_probe.log.  Kept, tested, reachable through mrisr_debug_force_tile.)
     static const int cand[] = {14, 15, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 45, 60, 61, 64, 65};  // (62, 63: fp8 operands, chosen by the launch, not the tuner)  // 27, 29-31 never won a shape (profiles/r01_gemm_sweep_tiles.log)
     for (int tile : cand) {
         const bool deep = false;
@@ -2207,6 +2262,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
             static const std::string skip = [] { const char* e = getenv("MRISR_TUNE_SKIP"); return std::string(e ? e : ""); }();
             if (!skip.empty() && ("," + skip + ",").find("," + std::to_string(tile) + ",") != std::string::npos) continue;
         }
+        if (tile >= 32 && tile <= 36 && !ring_ok(g, tile)) continue;  // counted-ring variants: exact plain GEMMs only
         if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
         if (tile >= 50 && tile < 60 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
         if (tile >= 60 && !rp_ok(g, tile)) continue;  // row-panel kernels: K = 320 / 640 row GEMMs
@@ -2214,7 +2270,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
         if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
         for (int s = 1; s <= 32; s *= 2) {
-            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50)) break;
+            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50 || (tile >= 32 && tile <= 36))) break;
             const size_t pbytes = s > 1 ? (size_t)s * g.M * g.N * 4 * zb : 0;
             if (pbytes > ((size_t)1 << 30)) break;
             if (s > 1 && g_ts.reserve(4, pbytes, false)) return 1;
@@ -2292,7 +2348,7 @@ int gemm_choose(GemmArgs& g, bool is_bf16) {
         plan(g, is_bf16, 0, &t, &s);
     }
     (void)cs;
-    if (t >= 60 && !rp_ok(g, t)) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
+    if ((t >= 60 && !rp_ok(g, t)) || (t >= 32 && t <= 36 && (!ring_ok(g, t) || s > 1))) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
     if (g_force_split > 1 && g.act != ACT_GEGLU && g.K / (is_bf16 ? 64 : 32) >= g_force_split && !g.lora_a) {
         s = g_force_split;
         if (t >= 50) t = is_bf16 ? 14 : 1;

@@ -329,6 +329,22 @@ def test_row_panel_kernel_many_workgroups_repeatable(M, N, K, tile):
         assert rel(a, u * F.gelu(gg)) < TOL["bf16"] and torch.equal(a, ops.ln_linear(xc, gc, bec, wc, bc, act=L.ACT_GEGLU))
 
 
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 36])
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (512, 1280, 2560), (256, 384, 192), (128, 128, 320)])
+def test_linear_counted_ring_kernel(tile, M, N, K):
+    """The 3- / 4-stage variants of the buffer-addressed kernel (counted vmcnt ring, NSTAGE - 1 K tiles in flight): K shorter
+    than, equal to and much longer than the ring, bias, GEGLU, repeatable bits."""
+    from mrisr import _lib as L
+    from mrisr import ops
+    x, w, b = _rnd((M, K), "bf16", 91), _rnd((N, K), "f32", 92, K ** -0.5), _rnd((N,), "f32", 93)
+    ref = F.linear(x.float(), w.to(torch.bfloat16).float(), b)
+    y = ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=tile)
+    assert rel(y, ref) < TOL["bf16"]
+    assert torch.equal(y, ops.linear(x.cuda(), w.cuda(), b.cuda(), tile=tile))
+    u, g = ref.chunk(2, dim=-1)
+    assert rel(ops.linear(x.cuda(), w.cuda(), b.cuda(), act=L.ACT_GEGLU, tile=tile), u * F.gelu(g)) < TOL["bf16"]
+
+
 def _fq(t):
     """e4m3 fake-quant with one scale per row (the scheme of the fp8 projections; oracle.unet.fp8_fake_quant_rows)."""
     sc = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-20) / 448.0
@@ -432,7 +448,7 @@ def test_unet_with_specialised_kernels_preferred():
     ref = ou.unet_forward({**up, **lora}, cfg, x, t, ctx)
     lib = L.lib()
     try:
-        for pref in (0, 50, 52, 41, 43, 60, 61, 64, 65):
+        for pref in (0, 50, 52, 41, 43, 60, 61, 64, 65):  # (ring tiles 32-36: test_unet_counted_ring_tiles_forced below)
             lib.mrisr_debug_prefer_tile(C.c_int(pref))
             net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
             net.load_state_dict({**up, **lora})

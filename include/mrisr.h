@@ -279,6 +279,10 @@ int mrisr_op_linear(const mrisr_tensor* x_rows, const float* w_dev, const float*
  * K = 320 or 640, n % 16 == 0) - the form the transformer blocks use for norm1/2/3 -> to_q|k|v / to_q / ff.net.0.proj */
 int mrisr_op_ln_linear(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, const float* w_dev,
                        const float* bias_dev, int n, int act, mrisr_tensor* y_rows, void* stream);
+/* y = [x +] FF2(GEGLU(FF1(LayerNorm(x)))) - the feed-forward of BasicTransformerBlock (diffusers attention.py: norm3 -> ff -> + hidden)
+ * in ONE kernel at C = 320 (bf16): w1 = ff.net.0.proj.weight [2*hidden][320], w2 = ff.net.2.weight [320][hidden], f32 on the device */
+int mrisr_op_mlp(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, const float* w1_dev, const float* b1_dev,
+                 const float* w2_dev, const float* b2_dev, int hidden, int residual, mrisr_tensor* y_rows, void* stream);
 /* the fp8 form of the same projection (BASELINE configs[4]): weights quantised to OCP e4m3 with one scale per output channel, the
  * rows with one scale per row inside the kernel, f32 accumulate; gamma_dev / beta_dev NULL = no LayerNorm prologue */
 int mrisr_op_linear_fp8(const mrisr_tensor* x_rows, const float* gamma_dev, const float* beta_dev, const float* w_dev,

@@ -35,6 +35,9 @@ void mrisr_autotune_release(void);
 int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int W, int stride, int ups, int c1, int tile, int splitk,
                      int iters, float* ms_out);
 
+/* micro-benchmark of the fused feed-forward kernel (tools/mlp_probe.py): M rows of width 320, random operands */
+int mrisr_bench_mlp(int M, int hidden, int iters, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

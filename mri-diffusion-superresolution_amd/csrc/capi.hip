@@ -1081,6 +1081,39 @@ int mrisr_op_ln_linear(const mrisr_tensor* x, const float* gamma_dev, const floa
     API_END
 }
 
+int mrisr_op_mlp(const mrisr_tensor* x, const float* gamma_dev, const float* beta_dev, const float* w1_dev, const float* b1_dev,
+                 const float* w2_dev, const float* b2_dev, int hidden, int residual, mrisr_tensor* y, void* stream) {
+    API_BEGIN
+    TRY(op_dtype_ok(x));
+    TRY(gemm_prepare());
+    MRISR_REQUIRE(x->ndim == 2 && y && y->ndim == 2 && y->dtype == x->dtype && x->dtype == MRISR_BF16, "bf16 rows in/out");
+    MRISR_REQUIRE(gamma_dev && beta_dev && w1_dev && w2_dev, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)x->shape[0], C = (int)x->shape[1], N2 = (int)y->shape[1];
+    MRISR_REQUIRE(y->shape[0] == M && mlp_fused_ok(C, hidden, N2), "fused feed-forward: C = 320 rows in and out, hidden % 32 == 0");
+    DevBuf w1p, b1p, w2b, w2p;
+    TRY(w1p.reserve((size_t)2 * hidden * C * 2, false));
+    TRY(w2b.reserve((size_t)N2 * hidden * 2, false));
+    TRY(w2p.reserve((size_t)N2 * hidden * 2, false));
+    TRY(launch_pack_rows<bf16>(w1_dev, 2 * hidden, C, w1p.p, C, 0, 0, 1, hidden, 1.0f, st));
+    TRY(launch_pack_rows<bf16>(w2_dev, N2, hidden, w2b.p, hidden, 0, 0, 0, 0, 1.0f, st));
+    TRY(launch_pack_mlp_w2(w2b.p, w2p.p, N2, hidden, st));
+    const float* b1 = nullptr;
+    if (b1_dev) {
+        TRY(b1p.reserve((size_t)2 * hidden * sizeof(float), false));
+        TRY(launch_pack_bias_geglu(b1_dev, static_cast<float*>(b1p.p), hidden, st));
+        b1 = static_cast<const float*>(b1p.p);
+    }
+    MlpArgs a;
+    a.x = x->data; a.ldx = C; a.M = M; a.ln_gamma = gamma_dev; a.ln_beta = beta_dev; a.ln_eps = 1e-5f;
+    a.w1 = w1p.p; a.b1 = b1; a.w2p = w2p.p; a.b2 = b2_dev;
+    a.resid = residual ? x->data : nullptr; a.ldr = C; a.out = y->data; a.ldo = N2; a.C = C; a.H = hidden; a.N2 = N2;
+    TRY(launch_mlp_fused(a, st));
+    MRISR_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+    API_END
+}
+
 int mrisr_op_linear_fp8(const mrisr_tensor* x, const float* gamma_dev, const float* beta_dev, const float* w_dev, const float* bias_dev,
                         int n, int act, mrisr_tensor* y, void* stream) {
     API_BEGIN
@@ -1229,6 +1262,43 @@ __global__ void fill_random_bf16_kernel(bf16* p, long long n, unsigned seed) {
     }
 }
 extern "C" void mrisr_debug_force_tile(int t);
+extern "C" int mrisr_bench_mlp(int M, int hidden, int iters, float* ms_out) {
+    API_BEGIN
+    TRY(gemm_prepare());
+    hipStream_t st = nullptr;
+    const int C = 320;
+    DevBuf x, w1, w2, o, b1, b2, gb;
+    TRY(x.reserve((size_t)M * C * 2, false));
+    TRY(o.reserve((size_t)M * C * 2, false));
+    TRY(w1.reserve((size_t)2 * hidden * C * 2, false));
+    TRY(w2.reserve((size_t)C * hidden * 2, false));
+    TRY(b1.reserve((size_t)2 * hidden * 4, true));
+    TRY(b2.reserve((size_t)C * 4, true));
+    TRY(gb.reserve((size_t)C * 4, true));
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(2048), dim3(256), 0, st, (bf16*)x.p, (long long)M * C, 1u);
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(2048), dim3(256), 0, st, (bf16*)w1.p, (long long)2 * hidden * C, 2u);
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(2048), dim3(256), 0, st, (bf16*)w2.p, (long long)C * hidden, 3u);
+    MlpArgs a;
+    a.x = x.p; a.ldx = C; a.M = M; a.ln_gamma = (const float*)gb.p; a.ln_beta = (const float*)gb.p;
+    a.w1 = w1.p; a.b1 = (const float*)b1.p; a.w2p = w2.p; a.b2 = (const float*)b2.p;
+    a.resid = x.p; a.ldr = C; a.out = o.p; a.ldo = C; a.C = C; a.H = hidden; a.N2 = C;
+    for (int i = 0; i < 2; ++i) TRY(launch_mlp_fused(a, st));
+    hipEvent_t e0, e1;
+    MRISR_CHECK_HIP(hipEventCreate(&e0));
+    MRISR_CHECK_HIP(hipEventCreate(&e1));
+    MRISR_CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) (void)launch_mlp_fused(a, st);
+    MRISR_CHECK_HIP(hipEventRecord(e1, st));
+    MRISR_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MRISR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+    API_END
+}
+
 extern "C" int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int W, int stride, int ups, int c1,
                                 int tile, int splitk, int iters, float* ms_out) {
     API_BEGIN

@@ -149,6 +149,19 @@ template <typename T> int launch_splitk_reduce(const GemmArgs& g, hipStream_t st
 const void* zero_page();  // >= 256 bytes of device zeros, valid after init_zero_page()
 int init_zero_page();
 int gemm_prepare();
+// fused feed-forward of a transformer block (C = 320): out = resid + FF2(GEGLU(FF1(LayerNorm(x)))), hidden activation on-chip
+struct MlpArgs {
+    const void* x = nullptr; int ldx = 0, M = 0;
+    const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
+    const void* w1 = nullptr; const float* b1 = nullptr;    // [2H][C] (u, gate) interleaved, bias alike
+    const void* w2p = nullptr; const float* b2 = nullptr;   // [N2][H] packed by launch_pack_mlp_w2
+    const void* resid = nullptr; int ldr = 0;
+    void* out = nullptr; int ldo = 0;
+    int C = 0, H = 0, N2 = 0;
+};
+bool mlp_fused_ok(int C, int H, int N2);
+int launch_pack_mlp_w2(const void* w2_bf16, void* dst, int N2, int H, hipStream_t st);
+int launch_mlp_fused(const MlpArgs& m, hipStream_t st);
 int gemm_rp_tile(const GemmArgs& g);  // row-panel kernel id for this (plain, short-K, bf16) GEMM, 0 if it is not eligible
 int gemm_choose(GemmArgs& g, bool is_bf16);  // sets g.tile / g.splitk (autotuned per signature for bf16)  // set launch attributes of every GEMM instantiation (call before graph capture)
 

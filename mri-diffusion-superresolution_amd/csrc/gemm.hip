@@ -1711,6 +1711,299 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
     }
 }
 
+// =================================================================================================
+// Fused feed-forward of a transformer block at C = 320 ("mlp"):  out = resid + FF2(GEGLU(FF1(LayerNorm(x)))) in ONE kernel.
+// The row-panel idea carried one GEMM further: a workgroup owns 128 rows (a wave: 32), keeps LayerNorm(x) in registers as
+// MFMA fragments (80 VGPRs) AND the whole 32 x 320 output tile of FF2 as accumulators (160 VGPRs) - one wave per SIMD, so a wave
+// may use the whole 512-register file.  The hidden activation never exists in memory: per chunk of 32 hidden units
+//   FF1:  64 interleaved (u, gate) weight rows x K = 320 from LDS  -> acc1 (starts at the bias)              80 MFMAs / wave
+//   GEGLU in registers: h = u * gelu(gate); the accumulator layout (lane: 4 consecutive columns of row fr) IS a valid second
+//         MFMA operand once the K order inside the 32-block is permuted - FF2's weight is packed with that permutation
+//         (launch_pack_mlp_w2), so h goes from FF1's accumulators to FF2's operand without leaving the lane;
+//   FF2:  one K step over those 32 hidden units against 320 weight rows from LDS -> acc2                       40 MFMAs / wave
+// Weights stream through LDS double buffered (W1 chunk 40 KB + W2 chunk 20 KB per stage, LDS-DMA, one barrier per chunk of 120
+// MFMAs).  Before: FF1 (row-panel, 75 us) wrote 84 MB of hidden activations that FF2 (tiled kernel, 66 us, K = 1280) read back
+// from HBM; 256 workgroups = one per CU for M = 32,768.
+// =================================================================================================
+struct MlpDev {
+    const void* x; int ldx; int M;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void* w1; const float* b1;   // [2H][320] (u, gate) interleaved in blocks of 16; bias interleaved alike (never null)
+    const void* w2p; const float* b2;  // [320][H], K permuted inside 32-blocks; bias [320] (never null)
+    const void* resid; int ldr;
+    void* out; int ldo; int H;
+};
+
+template <int KS, int DBG>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
+    typedef bf16 T;
+    constexpr int K = KS * 32, N2 = K, MF = 2, NF1 = 4, NF2 = N2 / 16;
+    constexpr int CH1 = 64 * K * 2;            // W1 chunk: 64 interleaved rows x K
+    constexpr int CH2 = N2 * 64;               // W2 chunk: N2 rows x 32 hidden (64 B)
+    constexpr int W2BASE = 2 * CH1;
+    constexpr int CPR = KS * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 128;
+    const int nchunks = a.H / 32;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)min((long long)a.M * a.ldx * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(a.w1, (unsigned)((long long)2 * a.H * K * 2));
+    const __amdgpu_buffer_rsrc_t r2 = make_rsrc(a.w2p, (unsigned)((long long)N2 * a.H * 2));
+
+    // DMA geometry.  W1 chunk: as in the row-panel kernel (row pitch K*2, 16-byte chunk c ^ (row & 7)).  W2 chunk: rows of 64 B
+    // (4 chunks), chunk q ^ g((row & 15) >> 2) with g = {0, 2, 3, 1}: conflict-free ds_read_b128 of 16 rows x one chunk
+    unsigned wvo1[10], wvo2[5];
+#pragma unroll
+    for (int p = 0; p < 10; ++p) {
+        const int L = (p * 4 + wave) * 64 + lane;
+        const int row = L / CPR, cs = L - row * CPR;
+        wvo1[p] = (unsigned)((row * K + (cs ^ (row & 7)) * 8) * 2);
+    }
+    const int gsw[4] = {0, 2, 3, 1};
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int L = (p * 4 + wave) * 64 + lane;
+        const int row = L >> 2, qs = L & 3;
+        const int q = qs ^ gsw[(row & 15) >> 2];
+        wvo2[p] = (unsigned)(((size_t)row * a.H + q * 8) * 2);
+    }
+    auto stage = [&](int c, int buf, bool live) {
+        const unsigned b1o = live ? (unsigned)c * (unsigned)CH1 : 0xC0000000u;
+        const unsigned b2o = live ? (unsigned)c * 64u : 0xC0000000u;
+#pragma unroll
+        for (int p = 0; p < 10; ++p) bl16(r1, smem + buf * CH1 + (p * 4 + wave) * 1024, wvo1[p], b1o);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) bl16(r2, smem + W2BASE + buf * CH2 + (p * 4 + wave) * 1024, wvo2[p], b2o);
+    };
+
+    // ---- the panel rows through LDS (the W1 buffers are still empty), then LayerNorm in registers ----
+    bf16x8 af[MF][KS];
+    {
+        char* areg = smem + wave * (32 * K * 2);
+#pragma unroll
+        for (int p = 0; p < 32 * CPR / 64; ++p) {
+            const int L = p * 64 + lane;
+            const int row = L / CPR, cs = L - row * CPR;
+            const int m = m0 + wave * 32 + row;
+            const unsigned vo = m < a.M ? (unsigned)(((size_t)m * a.ldx + (cs ^ (row & 7)) * 8) * 2) : BL_OOB;
+            bl16(rx, areg + p * 1024, vo, 0u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                af[j][kk] = *reinterpret_cast<const bf16x8*>(areg + (j * 16 + fr) * (K * 2) + (((kk * 4 + fg) ^ (fr & 7)) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    stage(0, 0, true);
+    {
+        float mean[MF], rstd[MF];
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const float c0 = __shfl((float)af[j][0][0], fr);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)af[j][kk][e] - c0; s1 += d; s2 = fmaf(d, d, s2); }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const float md = s1 * (1.0f / K);
+            mean[j] = c0 + md;
+            rstd[j] = rsqrtf(fmaxf(s2 * (1.0f / K) - md * md, 0.f) + a.ln_eps);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                rp_u4 w = __builtin_bit_cast(rp_u4, af[j][kk]);
+                asm volatile("" : "+v"(w));
+                af[j][kk] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        const float* gp = a.ln_gamma + fg * 8;
+        const float* bp = a.ln_beta + fg * 8;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + kk * 32), g1 = *reinterpret_cast<const f32x4*>(gp + kk * 32 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + kk * 32), b1 = *reinterpret_cast<const f32x4*>(bp + kk * 32 + 4);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+                    o[e] = (bf16)(((float)af[j][kk][e] - mean[j]) * rstd[j] * ga + be);
+                }
+                af[j][kk] = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- FF2 accumulators start at its bias ----
+    f32x4 acc2[NF2][MF];
+#pragma unroll
+    for (int i = 0; i < NF2; ++i) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.b2 + i * 16 + fg * 4);
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc2[i][j] = b;
+    }
+    float pbn[NF1][4];  // FF1 bias of the NEXT chunk (loaded a chunk ahead, behind the previous DMA)
+#pragma unroll
+    for (int i = 0; i < NF1; ++i) load4<float>(a.b1 + i * 16 + fg * 4, pbn[i]);
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c (weights + bias) has landed: issued one whole chunk ago
+        __syncthreads();
+        float pb[NF1][4];
+#pragma unroll
+        for (int i = 0; i < NF1; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pb[i][r] = pbn[i][r];
+        {
+            const int cn = min(c + 1, nchunks - 1);
+#pragma unroll
+            for (int i = 0; i < NF1; ++i) load4<float>(a.b1 + cn * 64 + i * 16 + fg * 4, pbn[i]);
+        }
+        stage(c + 1, buf ^ 1, c + 1 < nchunks && !(DBG & 1));
+        // ---- FF1 chunk ----
+        f32x4 acc1[NF1][MF];
+        const char* s1 = smem + buf * CH1 + fr * (K * 2);
+        bf16x8 wf[2][NF1];
+        auto load_w = [&](bf16x8 (&dst)[NF1], int kk) {
+            const int off = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+#pragma unroll
+            for (int i = 0; i < NF1; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(s1 + i * 16 * (K * 2) + off);
+        };
+        load_w(wf[0], 0);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+#pragma unroll
+            for (int i = 0; i < NF1; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc1[i][j];
+                    if (DBG & 4) { acc1[i][j] = cz; acc1[i][j][0] += (float)wf[kk & 1][i][0]; continue; }
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], af[j][kk], cz, 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- GEGLU in registers -> FF2's row operand: k elements 0..3 = hidden 4fg + r of block 0, 4..7 = of block 1 ----
+        bf16x8 h[MF];
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[j][p * 4 + r] = (DBG & 2) ? (bf16)(acc1[2 * p][j][r] + acc1[2 * p + 1][j][r])
+                                                             : (bf16)(acc1[2 * p][j][r] * gelu_erf_t<T>(acc1[2 * p + 1][j][r]));
+        // ---- FF2: one K step over these 32 hidden units ----
+        const char* s2 = smem + W2BASE + buf * CH2 + fr * 64 + ((fg ^ gsw[fr >> 2]) * 16);
+#pragma unroll
+        for (int i0 = 0; i0 < NF2; i0 += 4) {
+            bf16x8 w2f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w2f[u] = *reinterpret_cast<const bf16x8*>(s2 + (i0 + u) * 16 * 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    if (DBG & 8) { acc2[i0 + u][j][0] += (float)w2f[u][0] + (float)h[j][0]; continue; }
+                    acc2[i0 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[u], h[j], acc2[i0 + u][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- output: acc2 (+ residual) through a wave-private tile, whole rows ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int OP = N2 + 8;
+    T* wt = reinterpret_cast<T*>(smem + wave * (32 * OP * 2));
+#pragma unroll
+    for (int i = 0; i < NF2; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const bf16x4 o = {(bf16)acc2[i][j][0], (bf16)acc2[i][j][1], (bf16)acc2[i][j][2], (bf16)acc2[i][j][3]};
+            *reinterpret_cast<bf16x4*>(wt + (j * 16 + fr) * OP + i * 16 + fg * 4) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int CPRO = N2 / 8;
+    T* ob = reinterpret_cast<T*>(a.out);
+    const T* rb = reinterpret_cast<const T*>(a.resid);
+    for (int idx = lane; idx < 32 * CPRO; idx += 64) {
+        const int row = idx / CPRO, ch = idx - row * CPRO;
+        const int m = m0 + wave * 32 + row;
+        if (m >= a.M) continue;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(wt + row * OP + ch * 8);
+        if (rb) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(rb + (size_t)m * a.ldr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+        }
+        *reinterpret_cast<bf16x8*>(ob + (size_t)m * a.ldo + ch * 8) = v;
+    }
+}
+
+// FF2 weight [N2][H] (bf16, natural K order) -> K permuted inside every 32-block: position fg*8 + e holds hidden
+// (e < 4 ? 4 fg + e : 16 + 4 fg + e - 4), the order in which FF1's accumulator registers line up as an MFMA operand
+__global__ void pack_mlp_w2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int N2, int H) {
+    const long long total = (long long)N2 * H;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / H), k = (int)(i - (long long)n * H);
+        const int blk = k & ~31, pos = k & 31, fgp = pos >> 3, e = pos & 7;
+        const int srck = blk + (e < 4 ? 4 * fgp + e : 16 + 4 * fgp + (e - 4));
+        dst[i] = src[(size_t)n * H + srck];
+    }
+}
+int launch_pack_mlp_w2(const void* w2_bf16, void* dst, int N2, int H, hipStream_t st) {
+    MRISR_REQUIRE(H % 32 == 0, "fused feed-forward: hidden width a multiple of 32");
+    hipLaunchKernelGGL(pack_mlp_w2_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<const bf16*>(w2_bf16), reinterpret_cast<bf16*>(dst), N2, H);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// probe builds (MRISR_MLP_DBG; bits: 1 no weight DMA after chunk 0, 2 no GEGLU math, 4 no FF1 MFMAs, 8 no FF2 MFMAs); 0 = the product
+#define MLP_PROBES(X) X(0) X(1) X(2) X(4) X(8) X(12) X(14) X(15)
+bool mlp_fused_ok(int C, int H, int N2) {
+    static const int env = [] { const char* e = getenv("MRISR_MLP_FUSED"); return e ? atoi(e) : 1; }();
+    return env && C == 320 && N2 == 320 && H % 32 == 0 && H >= 64;
+}
+int launch_mlp_fused(const MlpArgs& m, hipStream_t st) {
+    MRISR_REQUIRE(mlp_fused_ok(m.C, m.H, m.N2), "fused feed-forward: C = N2 = 320");
+    MRISR_REQUIRE(m.x && m.w1 && m.w2p && m.out && m.ln_gamma && m.ln_beta && m.ldx % 8 == 0 && m.ldo % 8 == 0 && (!m.resid || m.ldr % 8 == 0),
+                  "fused feed-forward: operands");
+    MRISR_REQUIRE((size_t)std::max(2 * m.H, m.N2) * sizeof(float) <= kZeroPageBytes, "fused feed-forward: bias-free form beyond the zero page");
+    constexpr int smem = 2 * (64 * 320 * 2) + 2 * (320 * 64);
+    static const int dbg = [] { const char* e = getenv("MRISR_MLP_DBG"); return e ? atoi(e) : 0; }();
+    static bool attr = false;
+    if (!attr) {
+#define MLP_ATTR(D) MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MLP_PROBES(MLP_ATTR)
+#undef MLP_ATTR
+        attr = true;
+    }
+    MlpDev d;
+    d.x = m.x; d.ldx = m.ldx; d.M = m.M; d.ln_gamma = m.ln_gamma; d.ln_beta = m.ln_beta; d.ln_eps = m.ln_eps;
+    d.w1 = m.w1; d.b1 = m.b1 ? m.b1 : static_cast<const float*>(zero_page());
+    d.w2p = m.w2p; d.b2 = m.b2 ? m.b2 : static_cast<const float*>(zero_page());
+    d.resid = m.resid; d.ldr = m.ldr; d.out = m.out; d.ldo = m.ldo; d.H = m.H;
+    const double fl = 2.0 * m.M * ((double)2 * m.H * m.C + (double)m.H * m.N2);
+    const double by = 2.0 * ((double)m.M * m.C * (m.resid ? 3 : 2) + 3.0 * m.H * m.C);
+    ProfScope ps("mlp_fused_c320", fl, by, st);
+    bool launched = false;
+#define MLP_GO(D) if (dbg == D) { hipLaunchKernelGGL((mlp_fused_kernel<10, D>), dim3((m.M + 127) / 128), dim3(256), smem, st, d); launched = true; }
+    MLP_PROBES(MLP_GO)
+#undef MLP_GO
+    MRISR_REQUIRE(launched, "MRISR_MLP_DBG: no such probe build");
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const int nq = g.N >> 2;

@@ -15,6 +15,7 @@ struct XfW {
     int C = 0;
     NormW norm, ln1, ln2, ln3;
     LinW proj_in, proj_out, qkv, out1, q2, kv2, out2, ff1, ff2;
+    void* ff2p = nullptr;  // ff2.w with K permuted for the fused feed-forward kernel (bf16, C = 320 only)
     void* kc = nullptr;   // cached cross-attention K   [B*H][ctx_pad][dpad]
     void* vtc = nullptr;  // cached cross-attention V^T [B*H][dpad][ctx_pad]
 };

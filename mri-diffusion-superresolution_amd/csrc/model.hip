@@ -250,6 +250,12 @@ struct Packer {
         x.out2 = linear({b + ".attn2.to_out.0"});
         x.ff1 = linear({b + ".ff.net.0.proj"}, true);
         x.ff2 = linear({b + ".ff.net.2"});
+        // fused feed-forward (gemm.hip mlp_fused_kernel): FF2's weight once more, K permuted to FF1's accumulator order
+        if (sizeof(T) == 2 && !err && mlp_fused_ok(x.C, x.ff2.k, x.ff2.n) && x.ff1.n == 2 * x.ff2.k && !x.ff1.R && !x.ff2.R) {
+            x.ff2p = m.new_packed((size_t)x.ff2.n * x.ff2.k * sizeof(T), false);
+            if (!x.ff2p) { err = 4; return x; }
+            if (launch_pack_mlp_w2(x.ff2.w, x.ff2p, x.ff2.n, x.ff2.k, st)) err = 5;
+        }
         return x;
     }
 };

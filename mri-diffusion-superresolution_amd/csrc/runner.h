@@ -292,7 +292,13 @@ struct Runner {
         TRY(attention(hb, xw.kc, xw.vtc, m.ctx_len, m.ctx_pad, ao));
         TRY(linear(ao, M, C, xw.out2, ACT_NONE, t, C, nullptr, t, C));
         // GEGLU feed-forward
-        {
+        if (xw.ff2p && !m.keep && mlp_fused_ok(C, 4 * C, C)) {
+            MlpArgs a;
+            a.x = t; a.ldx = C; a.M = M; a.ln_gamma = xw.ln3.g; a.ln_beta = xw.ln3.b; a.ln_eps = 1e-5f;
+            a.w1 = xw.ff1.w; a.b1 = xw.ff1.b; a.w2p = xw.ff2p; a.b2 = xw.ff2.b;
+            a.resid = t; a.ldr = C; a.out = t; a.ldo = C; a.C = C; a.H = 4 * C; a.N2 = C;
+            if (!dry) TRY(launch_mlp_fused(a, st));
+        } else {
             T* ff = static_cast<T*>(alloc((size_t)M * 4 * C * sizeof(T)));
             if (!ff) return 7;
             TRY(linear(t, M, C, xw.ff1, ACT_GEGLU, nullptr, 0, nullptr, ff, 4 * C, nullptr, &xw.ln3, nrm));

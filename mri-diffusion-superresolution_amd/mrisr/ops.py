@@ -68,6 +68,21 @@ def ln_linear(x, gamma, beta, weight, bias=None, act=L.ACT_NONE):
     return y
 
 
+def mlp(x, gamma, beta, w1, b1, w2, b2, residual=True):
+    """x + FF2(GEGLU(FF1(LayerNorm(x)))) in one kernel (bf16 rows of width 320; the hidden activation stays on-chip):
+    w1 [2H][320] = diffusers ff.net.0.proj.weight (value half then gate half), w2 [320][H] = ff.net.2.weight."""
+    x = x.contiguous()
+    f = lambda t: t.detach().to(torch.float32).contiguous() if t is not None else None
+    ga, be, w1f, b1f, w2f, b2f = (f(t) for t in (gamma, beta, w1, b1, w2, b2))
+    hidden = w2f.shape[1]
+    y = torch.empty((x.shape[0], w2f.shape[0]), dtype=x.dtype, device=x.device)
+    tx, ty = L.as_tensor(x), L.as_tensor(y)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    L.check(L.lib().mrisr_op_mlp(C.byref(tx), p(ga), p(be), p(w1f), p(b1f), p(w2f), p(b2f), hidden, 1 if residual else 0,
+                                 C.byref(ty), L.stream_ptr()))
+    return y
+
+
 def linear_fp8(x, weight, bias=None, act=L.ACT_NONE, gamma=None, beta=None):
     """[LayerNorm(x)] W^T + bias with OCP e4m3 operands on the fp8 MFMA (row-panel kernel; bf16 in / out, K = 320 / 640)."""
     x = x.contiguous()

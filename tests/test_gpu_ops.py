@@ -329,6 +329,36 @@ def test_row_panel_kernel_many_workgroups_repeatable(M, N, K, tile):
         assert rel(a, u * F.gelu(gg)) < TOL["bf16"] and torch.equal(a, ops.ln_linear(xc, gc, bec, wc, bc, act=L.ACT_GEGLU))
 
 
+@pytest.mark.parametrize("M,H,bias,residual", [(128, 1280, True, True), (33000, 1280, True, True), (1000, 64, False, False),
+                                               (4096 + 77, 320, True, False)])
+def test_fused_feed_forward_kernel(M, H, bias, residual):
+    """norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + hidden in one kernel (C = 320; BasicTransformerBlock's feed-forward,
+    diffusers attention.py): against the f32 chain with the kernel's own rounding points (bf16 LayerNorm output, bf16 hidden
+    activation), ragged last panel, more panels than CUs, repeatable bits; and against the two-kernel path it replaces."""
+    from mrisr import _lib as L
+    from mrisr import ops
+    C = 320
+    x = (_rnd((M, C), "f32", 81) * 0.7 + 0.5).to(torch.bfloat16)
+    w1, b1 = _rnd((2 * H, C), "f32", 82, C ** -0.5), (_rnd((2 * H,), "f32", 83) if bias else None)
+    w2, b2 = _rnd((C, H), "f32", 84, H ** -0.5), (_rnd((C,), "f32", 85) if bias else None)
+    ga, be = 1 + 0.1 * _rnd((C,), "f32", 86), 0.1 * _rnd((C,), "f32", 87)
+    q = lambda t: t.to(torch.bfloat16).float()
+    xn = q(F.layer_norm(x.float(), (C,), ga, be, 1e-5))
+    u, g = F.linear(xn, q(w1), b1).chunk(2, dim=-1)
+    ref = F.linear(q(u * F.gelu(g)), q(w2), b2) + (x.float() if residual else 0)
+    c = lambda t: t.cuda() if t is not None else None
+    xc = x.cuda()
+    got = ops.mlp(xc, c(ga), c(be), c(w1), c(b1), c(w2), c(b2), residual=residual)
+    assert rel(got, ref) < TOL["bf16"], rel(got, ref)
+    assert float((got.float().cpu() - ref).abs().max()) < 0.05 * float(ref.abs().max())
+    for _ in range(3):
+        assert torch.equal(got, ops.mlp(xc, c(ga), c(be), c(w1), c(b1), c(w2), c(b2), residual=residual))
+    # the path it replaces: LayerNorm-prologue GEGLU projection, then the second projection (+ residual in f32 here)
+    hid = ops.ln_linear(xc, c(ga), c(be), c(w1), c(b1), act=L.ACT_GEGLU)
+    two = ops.linear(hid, c(w2), c(b2)).float() + (xc.float() if residual else 0)
+    assert rel(got, two) < TOL["bf16"], rel(got, two)
+
+
 @pytest.mark.parametrize("tile", [32, 33, 34, 35, 36])
 @pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (512, 1280, 2560), (256, 384, 192), (128, 128, 320)])
 def test_linear_counted_ring_kernel(tile, M, N, K):

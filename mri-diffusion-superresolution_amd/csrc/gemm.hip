@@ -1285,6 +1285,9 @@ __device__ __forceinline__ rp_f8x8 rp_quant8(const bf16x8& x, float inv_scale) {
 // two co-resident workgroups put ONE wave on each SIMD, which may then use the whole 512-register file - K = 640 rows (160
 // registers of fragments per lane) fit without spilling, and a 64 x 640 panel is 80 KB = the weight buffers, so it can come in
 // through LDS as whole pieces too).
+#ifndef RP_READS_FIRST
+#define RP_READS_FIRST 1
+#endif
 template <int KS, int NF, bool LORA, int PRO, bool FP8, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const GemmArgs g) {
     typedef bf16 T;
@@ -1567,6 +1570,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+                if (RP_READS_FIRST) __builtin_amdgcn_sched_barrier(0);  // else the scheduler sinks the prefetch to the end of the step
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -1594,6 +1598,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+                if (RP_READS_FIRST) __builtin_amdgcn_sched_barrier(0);  // else the scheduler sinks the prefetch to the end of the step
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -1761,12 +1766,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
         const int row = L / CPR, cs = L - row * CPR;
         wvo1[p] = (unsigned)((row * K + (cs ^ (row & 7)) * 8) * 2);
     }
-    const int gsw[4] = {0, 2, 3, 1};
+    auto gsw = [](int x) { return (0x78 >> (2 * x)) & 3; };  // {0, 2, 3, 1}
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
         const int L = (p * 4 + wave) * 64 + lane;
         const int row = L >> 2, qs = L & 3;
-        const int q = qs ^ gsw[(row & 15) >> 2];
+        const int q = qs ^ gsw((row & 15) >> 2);
         wvo2[p] = (unsigned)(((size_t)row * a.H + q * 8) * 2);
     }
     auto stage = [&](int c, int buf, bool live) {
@@ -1850,6 +1855,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
 #pragma unroll
         for (int j = 0; j < MF; ++j) acc2[i][j] = b;
     }
+    const int s2off = fr * 64 + ((fg ^ gsw(fr >> 2)) * 16);
     float pbn[NF1][4];  // FF1 bias of the NEXT chunk (loaded a chunk ahead, behind the previous DMA)
 #pragma unroll
     for (int i = 0; i < NF1; ++i) load4<float>(a.b1 + i * 16 + fg * 4, pbn[i]);
@@ -1882,6 +1888,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+            __builtin_amdgcn_sched_barrier(0);  // the reads first: the scheduler otherwise sinks them to the end of the step
 #pragma unroll
             for (int i = 0; i < NF1; ++i)
 #pragma unroll
@@ -1903,18 +1910,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
                     h[j][p * 4 + r] = (DBG & 2) ? (bf16)(acc1[2 * p][j][r] + acc1[2 * p + 1][j][r])
                                                              : (bf16)(acc1[2 * p][j][r] * gelu_erf_t<T>(acc1[2 * p + 1][j][r]));
         // ---- FF2: one K step over these 32 hidden units ----
-        const char* s2 = smem + W2BASE + buf * CH2 + fr * 64 + ((fg ^ gsw[fr >> 2]) * 16);
+        const char* s2 = smem + W2BASE + buf * CH2 + s2off;
+        bf16x8 w2f[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w2f[0][u] = *reinterpret_cast<const bf16x8*>(s2 + u * 16 * 64);
 #pragma unroll
         for (int i0 = 0; i0 < NF2; i0 += 4) {
-            bf16x8 w2f[4];
+            const int cur = (i0 >> 2) & 1;
+            if (i0 + 4 < NF2) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w2f[u] = *reinterpret_cast<const bf16x8*>(s2 + (i0 + u) * 16 * 64);
+                for (int u = 0; u < 4; ++u) w2f[cur ^ 1][u] = *reinterpret_cast<const bf16x8*>(s2 + (i0 + 4 + u) * 16 * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < MF; ++j) {
-                    if (DBG & 8) { acc2[i0 + u][j][0] += (float)w2f[u][0] + (float)h[j][0]; continue; }
-                    acc2[i0 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[u], h[j], acc2[i0 + u][j], 0, 0, 0);
+                    if (DBG & 8) { acc2[i0 + u][j][0] += (float)w2f[cur][u][0] + (float)h[j][0]; continue; }
+                    acc2[i0 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[cur][u], h[j], acc2[i0 + u][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -35,6 +35,10 @@ void mrisr_autotune_release(void);
 int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int W, int stride, int ups, int c1, int tile, int splitk,
                      int iters, float* ms_out);
 
+/* split-K: 1 the last split of a tile to arrive reduces inside the GEMM kernel, 0 the separate reduce kernel,
+ * -1 (default) as MRISR_SK_INKERNEL says (unset: the reduce kernel - measured no slower, see gemm.hip sk_counters_for) */
+void mrisr_debug_sk_inkernel(int on);
+
 /* micro-benchmark of the fused feed-forward kernel (tools/mlp_probe.py): M rows of width 320, random operands */
 int mrisr_bench_mlp(int M, int hidden, int iters, float* ms_out);
 

@@ -100,6 +100,9 @@ struct GemmArgs {
     // ---- split-K (blockIdx.y); partials go to `partial` as f32 [split][M][N] ----
     int splitk = 1;
     float* partial = nullptr;
+    // per-tile arrival counters (zero between launches): the last split of a tile to arrive sums the slabs and runs the kernel's own
+    // epilogue, so no separate reduce launch follows (set by launch_gemm for the bf16 DMA kernels; null = splitk_reduce_kernel)
+    unsigned* sk_counters = nullptr;
     // ---- epilogue ----
     float alpha = 1.0f;
     const float* bias = nullptr;    // [N] (GEGLU: interleaved like the weight rows)

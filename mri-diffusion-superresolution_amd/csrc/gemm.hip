@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <unordered_map>
 
 namespace mrisr {
 
@@ -562,6 +564,46 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 // load latency.  Deeper rings with a counted vmcnt were tried twice (8-wave kernels, and 3-stage 4-wave variants on
 // in-range shapes) and lost every time (profiles/r01_gemm_sweep_incl_deep_stages.log, profiles/r01b_ws_sweep.log); note that
 // a fully out-of-range LDS-DMA instruction retires out of order, so a counted wait is only safe without padding rows.
+// ---- split-K, second half inside the GEMM kernel ------------------------------------------------------------------------------
+// Every split stores its f32 tile to its slab, releases it (agent-scope fence: the slab leaves this XCD's L2) and takes a ticket on
+// the tile's counter; the LAST split to arrive acquires, re-reads all slabs in split order (its own included: the sum is the same
+// bits whichever split arrives last) into its accumulators, resets the counter for the next launch and falls through to the
+// kernel's normal epilogue.  Returns true in the workgroup that goes on.  `ticket_lds`: 4 bytes of drained LDS.
+template <int NF, int MF>
+__device__ __forceinline__ bool splitk_last_arriver(const GemmArgs& g, f32x4 (&acc)[NF][MF], unsigned tile_idx, const float* slab0, int m_base, int n_base,
+                                                    int fr, int fg, char* ticket_lds) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *reinterpret_cast<volatile unsigned*>(ticket_lds) = __hip_atomic_fetch_add(g.sk_counters + tile_idx, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<volatile unsigned*>(ticket_lds);
+    if (ticket != (unsigned)g.splitk - 1) return false;
+    __syncthreads();  // the ticket word may be overwritten by the epilogue's staging from here on
+    if (threadIdx.x == 0) __hip_atomic_store(g.sk_counters + tile_idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const size_t slab = (size_t)g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.splitk; ++s) {
+        const float* p = slab0 + (size_t)s * slab;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m_base + j * 16 + fr;
+                const int n = n_base + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)m * g.N + n));
+                    acc[i][j] += t;
+                }
+            }
+    }
+    return true;
+}
+
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool LORA>
 __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  // 2 waves / SIMD: two workgroups per CU hide each other's loads
     // NSTAGE 3 / 4 (round 2): a ring with a COUNTED vmcnt - NSTAGE - 1 K tiles in flight per workgroup.  For the shapes whose
@@ -865,7 +907,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
                     store4<float>(part + (size_t)m * g.N + n, v);
                 }
             }
-        return;
+        // (the widest tiles keep the separate reduce kernel: the slab loop on top of 24+ accumulator fragments spills)
+        if constexpr (NF * MF > 20) return;
+        else {
+            if (!g.sk_counters) return;
+            if (!splitk_last_arriver<NF, MF>(g, acc, (unsigned)(z * gridDim.x + blockIdx.x), g.partial + (size_t)z * g.splitk * (size_t)g.M * g.N,
+                                             m0 + wm0, n0 + wn0, fr, fg, smem))
+                return;
+        }
     }
     float pb[NF][4];
     preload_cols<NF>(g, n0 + wn0 + fg * 4, pb);
@@ -1104,7 +1153,11 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
                     store4<float>(part + (size_t)m * g.N + n, v);
                 }
             }
-        return;
+        if constexpr (NF * MF > 20) return;
+        else {
+            if (!g.sk_counters) return;
+            if (!splitk_last_arriver<NF, MF>(g, acc, blockIdx.x, g.partial, m0 + wm0, n0 + wn0, fr, fg, smem)) return;
+        }
     }
     constexpr int OPITCH = BN + 8;  // staged row output, as in gemm_bl_kernel (patch + weight stages are drained)
     T* otile = reinterpret_cast<T*>(smem);
@@ -2672,6 +2725,41 @@ int gemm_prepare() {
     return prepare_bls();
 }
 
+// per-stream arrival counters for the in-kernel split-K reduction: launches on one stream are ordered and every launch leaves its
+// counters at zero, so one zeroed array per stream serves them all.  Not created during stream capture (the eager warm-up on the same
+// stream has created it before; otherwise the launch falls back to the separate reduce kernel).
+// OFF by default (MRISR_SK_INKERNEL=1 turns it on): measured on the bench workload it is no faster than the reduce launches it removes -
+// 10.92 vs 10.82 ms per denoising step in the replayed graph (41 fewer launches, but every workgroup's agent-scope release is an L2
+// write-back and the last arriver's tail is latency-bound); launched eagerly the split GEMMs take 3-4x longer (M=512 s=8 conv: 33 ->
+// 138 us), profiles/r02m_splitk_inkernel.log.  Kept as a tested alternative (tests/test_gpu_ops.py::test_splitk_reduced_inside_the_gemm_kernel).
+static bool tile_reduces_in_kernel(int tile) {
+#define X(id, bm, bn, wm, wn, ...) if (tile == id) return ((bm) / (wm) / 16) * ((bn) / (wn) / 16) <= 20;  // as the kernels' `if constexpr`
+    BL_CFGS(X)
+    HALO_CFGS(X)
+#undef X
+    return false;
+}
+static long long tile_count(int, const GemmArgs& g) { return (long long)((g.M + 63) / 64) * ((g.N + 63) / 64); }  // upper bound: no tile is smaller than 64 x 64
+static constexpr int kSkCounters = 16384;
+static int g_sk_inkernel = -1;  // test hook: 0 = the separate reduce kernel, 1 = in-kernel, -1 = MRISR_SK_INKERNEL (default 0)
+extern "C" void mrisr_debug_sk_inkernel(int on) { g_sk_inkernel = on; }
+static std::mutex g_sk_mu;
+static std::unordered_map<hipStream_t, unsigned*> g_sk_map;
+static unsigned* sk_counters_for(hipStream_t st) {
+    static const int env = [] { const char* e = getenv("MRISR_SK_INKERNEL"); return e ? atoi(e) : 0; }();
+    if (g_sk_inkernel < 0 ? !env : !g_sk_inkernel) return nullptr;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    auto it = g_sk_map.find(st);
+    if (it != g_sk_map.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) return nullptr;
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, kSkCounters * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kSkCounters * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_sk_map[st] = p;
+    return p;
+}
+
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
@@ -2689,6 +2777,12 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     int tile = g.tile ? g.tile : g_force_tile, s = g.splitk;
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
     if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;
+    // split-K: the bf16 DMA kernels (tiled and halo) finish the reduction themselves
+    const_cast<GemmArgs&>(g).sk_counters = nullptr;
+    if (g.splitk > 1 && sizeof(T) == 2 && tile_reduces_in_kernel(tile)) {
+        const long long ntiles = tile_count(tile, g) * (long long)g.batch;
+        if (ntiles > 0 && ntiles <= kSkCounters) const_cast<GemmArgs&>(g).sk_counters = sk_counters_for(st);
+    }
     int rc;
     switch (tile) {
         case 2: rc = launch_cfg<T, 256, 64, 4, 1>(g, st); break;
@@ -2709,7 +2803,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
     }
     if (rc) return rc;
-    if (g.splitk > 1) return launch_splitk_reduce<T>(g, st);
+    if (g.splitk > 1 && !g.sk_counters) return launch_splitk_reduce<T>(g, st);
     return 0;
 }
 

@@ -329,6 +329,42 @@ def test_row_panel_kernel_many_workgroups_repeatable(M, N, K, tile):
         assert rel(a, u * F.gelu(gg)) < TOL["bf16"] and torch.equal(a, ops.ln_linear(xc, gc, bec, wc, bc, act=L.ACT_GEGLU))
 
 
+@pytest.mark.parametrize("kind,shape,tile,splitk", [
+    ("lin", (2048, 1280, 5120), 26, 2), ("lin", (512, 1280, 2560), 17, 4), ("lin", (2048 - 40, 1280 - 32, 5120), 25, 4),
+    ("conv", (32, 1280, 1280, 4), 26, 8), ("conv", (8, 640, 640, 16), 43, 2), ("conv", (2, 1280, 640, 32), 41, 4)])
+def test_splitk_reduced_inside_the_gemm_kernel(kind, shape, tile, splitk):
+    """Split-K without the reduce launch: the last split of a tile to arrive sums the f32 slabs in split order and runs the kernel's
+    own epilogue.  Same bits as the separate reduce kernel (same order of the same f32 additions), the same bits on every repeat
+    whichever split arrives last (30 launches, many more tiles x splits than CUs), the counters back at zero (the second and later
+    launches would otherwise never reduce), ragged edges, and right against the f32 reference."""
+    from mrisr import _lib as L
+    from mrisr import ops
+    lib = L.lib()
+    if kind == "lin":
+        M, N, K = shape
+        x, w, b = _rnd((M, K), "bf16", 91), _rnd((N, K), "f32", 92, K ** -0.5), _rnd((N,), "f32", 93)
+        ref = F.linear(x.float(), w.to(torch.bfloat16).float(), b)
+        xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+        run = lambda: ops.linear(xc, wc, bc, tile=tile, splitk=splitk)
+    else:
+        B, Cin, Cout, H = shape
+        x, w, b = _rnd((B, Cin, H, H), "bf16", 94), _rnd((Cout, Cin, 3, 3), "f32", 95, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 96)
+        ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, padding=1)
+        xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+        run = lambda: ops.conv3x3(xc, wc, bc, tile=tile, splitk=splitk)
+    try:
+        lib.mrisr_debug_sk_inkernel(0)
+        two_pass = run()
+        lib.mrisr_debug_sk_inkernel(1)
+        first = run()
+        assert rel(first, ref) < TOL["bf16"], rel(first, ref)
+        assert torch.equal(first, two_pass), float((first.float() - two_pass.float()).abs().max())
+        for rep in range(30):
+            assert torch.equal(run(), first), rep
+    finally:
+        lib.mrisr_debug_sk_inkernel(-1)
+
+
 @pytest.mark.parametrize("M,H,bias,residual", [(128, 1280, True, True), (33000, 1280, True, True), (1000, 64, False, False),
                                                (4096 + 77, 320, True, False)])
 def test_fused_feed_forward_kernel(M, H, bias, residual):

@@ -485,13 +485,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g, const char*
 // beyond num_records: the hardware range check returns zeros, no zero page and no select.
 // =================================================================================================
 // staged epilogue: the tile sits in LDS as [BM][pitch] T; write it out row by row, 16 bytes per lane
-template <int BM, int BN>
+template <int BM, int BN, int NT = 256>
 __device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* otile, int pitch, int m0, int n0, int z, bool add_resid) {
     __syncthreads();
     constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
     bf16* out = reinterpret_cast<bf16*>(g.out) + (size_t)z * g.o_bs;
     const bf16* res = add_resid ? reinterpret_cast<const bf16*>(g.resid) + (size_t)z * g.o_bs : nullptr;
-    for (int idx = threadIdx.x; idx < BM * CPR; idx += 256) {
+    for (int idx = threadIdx.x; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = m0 + row, n = n0 + ch * 8;
         if (m >= g.M || n >= g.N) continue;
@@ -1178,6 +1178,225 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
             }
         }
     if (staged) copy_out_tile<BM, BN>(g, otile, OPITCH, m0, n0, 0, resid_later);
+}
+
+// =================================================================================================
+// Halo conv kernel, 256-row tiles ("halo8"): eight waves (4 x 2, a wave: 64 x BN/2 as in the 128 x 160 halo kernel) share ONE
+// weight tile per (tap, chunk) phase.  The 128-row kernel runs two workgroups per CU that each fetch their own copy of the
+// weight tile - 87 % of its LDS fill - and keeps one 20 KB stage per workgroup in flight, which at ~1.2 us of L2 latency
+// under load caps the fill near 33 GB/s per CU: 3,500 cycles per phase against 1,290 cycles of MFMA work (level-0 convs at
+// 0.9 PF).  Here the weight fill per MAC is halved and the LDS the second workgroup's copies occupied becomes a ring of
+// NSTAGE weight stages, filled NSTAGE - 1 phases ahead with counted waits (every wave issues the same number of DMA
+// instructions per stage, none fully out of range).  The patch (TH + 2 rows of W + 2 pixels x 64 channels) is single
+// buffered: its fill is exposed once per 9 phases.
+// =================================================================================================
+template <int BN, int NSTAGE>
+__global__ __launch_bounds__(512, 2) void gemm_halo8_kernel(const GemmArgs g) {
+    typedef bf16 T;
+    constexpr int BM = 256, NT = 512, BK = 64, WGN = 2;
+    constexpr int WTM = 64, WTN = BN / WGN;
+    constexpr int MF = WTM / 16, NF = WTN / 16;
+    constexpr int W_IT = (BN * 8 + NT - 1) / NT;   // DMA rounds (one instruction per wave each) per weight stage
+    constexpr int WSTAGE = W_IT * NT * 16;
+    constexpr int PIT_MAX = 7;                     // 16-byte transfers per thread for the largest supported patch (W = 64: 6 x 66 pixels)
+    constexpr int D = NSTAGE - 1;                  // prefetch distance in phases
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 weight stages");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.y;
+    const int Wd = g.Win, Hd = g.Hin;
+    const int TH = BM / Wd, PW = Wd + 2;
+    const int npix = (TH + 2) * PW;
+    const int pit = (npix * 8 + NT - 1) / NT;
+    char* patch = smem;
+    char* wbase = smem + pit * (NT * 16);
+
+    const int ntn = (g.N + BN - 1) / BN;
+    const int ntm = g.M / BM;
+    const int nblk = ntn * ntm;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int tn, tm;
+    {
+        const int GM = g.group_m > 1 ? g.group_m : 1;
+        const int per_group = GM * ntn;
+        const int grp = logical / per_group;
+        const int first_m = grp * GM;
+        const int gsz = min(GM, ntm - first_m);
+        const int within = logical - grp * per_group;
+        tm = first_m + within % gsz;
+        tn = within / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int img = m0 / (Hd * Wd);
+    const int y0 = (m0 - img * Hd * Wd) / Wd;
+
+    const T* a0p = reinterpret_cast<const T*>(g.a0);
+    const T* a1p = reinterpret_cast<const T*>(g.a1);
+    const T* wp = reinterpret_cast<const T*>(g.w);
+    const long long a_rows = (long long)g.B * Hd * Wd;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wp, (unsigned)min((long long)g.N * g.K * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(a0p, (unsigned)min(a_rows * g.lda0 * 2, 0x7FFFFFFFll));
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(a1p ? (const void*)a1p : (const void*)a0p,
+                                                 a1p ? (unsigned)min(a_rows * g.lda1 * 2, 0x7FFFFFFFll) : 0u);
+
+    // weight rows: transfer t = it * 512 + tid carries chunk (t & 7) of tile row (t >> 3); rows past the tile / past N are
+    // clamped (a copy lands in the stage's unused tail or in columns the epilogue never stores): no out-of-range instruction
+    const int lrow = tid >> 3, pch = tid & 7;
+    unsigned wvo[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int row = it * (NT / 8) + lrow;
+        const int n = min(n0 + min(row, BN - 1), g.N - 1);
+        const int c = pch ^ (row & 7);
+        wvo[it] = (unsigned)(((size_t)n * g.K + c * 8) * 2);
+    }
+    unsigned pvo0[PIT_MAX], pvo1[PIT_MAX];
+#pragma unroll
+    for (int it = 0; it < PIT_MAX; ++it) {
+        const int t = it * NT + tid;
+        const int pp = t >> 3;
+        const int c = (t & 7) ^ (pp & 7);
+        const int hy = pp / PW, hx = pp - hy * PW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = pp < npix && iy >= 0 && iy < Hd && ix >= 0 && ix < Wd;
+        const unsigned pix = (unsigned)((img * Hd + iy) * Wd + ix);
+        pvo0[it] = ok ? (pix * (unsigned)g.lda0 + (unsigned)c * 8u) * 2u : BL_OOB;
+        pvo1[it] = ok ? (pix * (unsigned)g.lda1 + (unsigned)c * 8u) * 2u : BL_OOB;
+    }
+
+    const int Ct = g.c0 + g.c1;
+    const int nch = Ct / BK;
+    const int per = (nch + g.splitk - 1) / g.splitk;
+    const int ch_beg = split * per, ch_end = min(nch, ch_beg + per);
+    const int P = (ch_end - ch_beg) * 9;           // phases of this workgroup: (chunk, tap) pairs
+
+    auto stage_patch = [&](int ch) {
+        const int cc = ch * BK;
+        const bool second = cc >= g.c0;
+        const unsigned chb = (unsigned)(second ? cc - g.c0 : cc) * 2;
+#pragma unroll
+        for (int it = 0; it < PIT_MAX; ++it) {
+            if (it < pit) {
+                if (!second) bl16(ra0, patch + (it * NT + wave * 64) * 16, pvo0[it], chb);
+                else bl16(ra1, patch + (it * NT + wave * 64) * 16, pvo1[it], chb);
+            }
+        }
+    };
+    auto stage_w = [&](int p) {  // phase p -> ring slot p % NSTAGE
+        const int ch = ch_beg + p / 9, tap = p - (p / 9) * 9;
+        char* sb = wbase + (p % NSTAGE) * WSTAGE;
+        const unsigned kb = (unsigned)(tap * Ct + ch * BK) * 2;
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) bl16(rw, sb + (it * NT + wave * 64) * 16, wvo[it], kb);
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm0 = (wave / WGN) * WTM, wn0 = (wave % WGN) * WTN;
+    const int fr = lane & 15, fg = lane >> 4;
+    int prow[MF];
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+        const int p = wm0 + j * 16 + fr;
+        const int ty = p / Wd, tx = p - ty * Wd;
+        prow[j] = ty * PW + tx;
+    }
+
+    auto compute = [&](int p) {
+        const char* sw = wbase + (p % NSTAGE) * WSTAGE;
+        const int tap = p - (p / 9) * 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int toff = ky * PW + kx;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int physw = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            bf16x8 wf[NF], af[MF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sw + (wn0 + i * 16 + fr) * 128 + physw);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int pr = prow[j] + toff;
+                af[j] = *reinterpret_cast<const bf16x8*>(patch + pr * 128 + (((kk * 4 + fg) ^ (pr & 7)) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (P > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < P) stage_w(d);
+        stage_patch(ch_beg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int p = 0; p < P; ++p) {
+            if (p + D < P) stage_w(p + D);  // into the slot phase p - 1 read: free since the barrier that ended it
+            compute(p);
+            const int tap = p - (p / 9) * 9;
+            if (tap == 8 && p + 1 < P) {
+                __syncthreads();  // every wave is done with this chunk's patch
+                stage_patch(ch_beg + (p + 1) / 9);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                // phase p + 1's weights must have landed; the stages issued after them (phases p + 2 .. p + D) may stay in flight
+                const int young = min(D - 1, P - 2 - p);
+                if (young >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_IT) : "memory");
+                else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_IT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+    }
+
+    if (g.splitk > 1) {
+        float* part = g.partial + (size_t)split * (size_t)g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = m0 + wm0 + j * 16 + fr;
+                const int n = n0 + wn0 + i * 16 + fg * 4;
+                if (m < g.M && n < g.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4<float>(part + (size_t)m * g.N + n, v);
+                }
+            }
+        return;
+    }
+    constexpr int OPITCH = BN + 8;
+    T* otile = reinterpret_cast<T*>(smem);
+    const bool staged = g.out_mode == OUT_ROWS && (g.ldo & 7) == 0 && (size_t)BM * OPITCH * 2 <= (size_t)pit * (NT * 16) + NSTAGE * WSTAGE && g.stage_out > 1;
+    const bool resid_later = staged && g.resid != nullptr && (g.ldr & 7) == 0 && g.stage_out < 3;
+    float pb[NF][4];
+    preload_cols<NF>(g, n0 + wn0 + fg * 4, pb);
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wm0 + j * 16 + fr;
+            const int n = n0 + wn0 + i * 16 + fg * 4;
+            if (m < g.M && n < g.N) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue4<T>(g, 0, m, n, v, nullptr, nullptr, staged ? otile + (m - m0) * OPITCH + (n - n0) : nullptr, resid_later, true, nullptr,
+                             0, 0, 0, pb[i]);
+            }
+        }
+    if (staged) copy_out_tile<BM, BN, NT>(g, otile, OPITCH, m0, n0, 0, resid_later);
 }
 
 // =================================================================================================
@@ -2282,6 +2501,51 @@ static int halo_bm(int tile) {
     return 0;
 }
 
+// 256-row halo kernel (eight waves): id -> <BN, weight stages>
+#define HALO8_CFGS(X) \
+    X(46, 160, 2)     \
+    X(47, 160, 3)     \
+    X(48, 160, 4)
+static bool is_halo8(int tile) { return tile >= 46 && tile <= 48; }
+static bool halo8_ok(const GemmArgs& g) {
+    if (!g.conv || g.stride != 1 || g.ups != 0 || g.zstuff || g.batch != 1 || g.pad != 1) return false;
+    if (g.Win % 8 != 0 || g.Win > 64 || 256 % g.Win != 0) return false;
+    if ((g.Hin * g.Win) % 256 != 0 || g.M % 256 != 0 || g.Hout != g.Hin || g.Wout != g.Win) return false;
+    const int npix = (256 / g.Win + 2) * (g.Win + 2);
+    return (npix * 8 + 511) / 512 <= 7 && g.N % 4 == 0;
+}
+template <int BN, int NSTAGE>
+static int launch_halo8(const GemmArgs& g, hipStream_t st) {
+    MRISR_REQUIRE(halo8_ok(g), "256-row halo conv kernel: unsupported geometry");
+    const int npix = (256 / g.Win + 2) * (g.Win + 2);
+    const size_t smem = (size_t)((npix * 8 + 511) / 512) * 8192 + (size_t)NSTAGE * ((BN * 8 + 511) / 512) * 8192;
+    MRISR_REQUIRE(smem <= 160 * 1024, "256-row halo conv kernel: LDS");
+    static bool attr = false;
+    if (!attr) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_halo8_kernel<BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const int ntn = (g.N + BN - 1) / BN, ntm = g.M / 256;
+    const_cast<GemmArgs&>(g).group_m = auto_group_m(ntm, ntn, 256, BN);
+    dim3 grid(ntn * ntm, g.splitk, 1);
+    static const std::string base_name = std::string("gemm_bf16_halo256x") + std::to_string(BN) + "r" + std::to_string(NSTAGE);
+    std::string pname = base_name;
+    if (prof_enabled() && prof_shapes()) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s conv M=%d N=%d K=%d s=%d b=%d", base_name.c_str(), g.M, g.N, g.K, g.splitk, g.batch);
+        pname = buf;
+    }
+    double fl = g.alg_flops, by = g.alg_bytes;
+    if (prof_enabled()) {
+        if (fl == 0.0) fl = 2.0 * g.M * (double)g.N * g.K;
+        if (by == 0.0) by = 2.0 * ((double)g.B * g.Hin * g.Win * (g.c0 + g.c1) + (double)g.N * g.K + (double)g.M * g.N);
+    }
+    ProfScope ps(prof_intern(pname), fl, by, st);
+    hipLaunchKernelGGL((gemm_halo8_kernel<BN, NSTAGE>), grid, dim3(512), smem, st, g);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // weight-stationary configurations: id -> <KS, NB>   (K = 32*KS, slab of 16*NB output columns)
 #define WS_CFGS(X)   \
     X(50, 10, 10)    \
@@ -2622,7 +2886,8 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
             if (!skip.empty() && ("," + skip + ",").find("," + std::to_string(tile) + ",") != std::string::npos) continue;
         }
         if (tile >= 32 && tile <= 36 && !ring_ok(g, tile)) continue;  // counted-ring variants: exact plain GEMMs only
-        if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
+        if (is_halo8(tile)) { if (!halo8_ok(g)) continue; }
+        else if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
         if (tile >= 50 && tile < 60 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
         if (tile >= 60 && !rp_ok(g, tile)) continue;  // row-panel kernels: K = 320 / 640 row GEMMs
         // 5 fragments per wave along N (BN = 160): no (u, gate) pairing for the GEGLU epilogue
@@ -2695,7 +2960,7 @@ int gemm_choose(GemmArgs& g, bool is_bf16) {
     }
     if (g_force_tile) { g.tile = g_force_tile; if (g.splitk < 1) g.splitk = 1; return 0; }
     if (g_prefer_tile && is_bf16 && bl_ok(g) &&
-        ((g_prefer_tile >= 60 && rp_ok(g, g_prefer_tile)) || (g_prefer_tile >= 50 && g_prefer_tile < 60 && ws_ok(g, g_prefer_tile)) || (g_prefer_tile >= 40 && g_prefer_tile < 50 && halo_ok(g, halo_bm(g_prefer_tile))))) {
+        ((g_prefer_tile >= 60 && rp_ok(g, g_prefer_tile)) || (g_prefer_tile >= 50 && g_prefer_tile < 60 && ws_ok(g, g_prefer_tile)) || (g_prefer_tile >= 40 && g_prefer_tile < 50 && (is_halo8(g_prefer_tile) ? halo8_ok(g) : halo_ok(g, halo_bm(g_prefer_tile)))))) {
         g.tile = g_prefer_tile;
         g.splitk = 1;
         return 0;
@@ -2707,7 +2972,7 @@ int gemm_choose(GemmArgs& g, bool is_bf16) {
         plan(g, is_bf16, 0, &t, &s);
     }
     (void)cs;
-    if ((t >= 60 && !rp_ok(g, t)) || (t >= 32 && t <= 36 && (!ring_ok(g, t) || s > 1))) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
+    if ((t >= 60 && !rp_ok(g, t)) || (t >= 32 && t <= 36 && (!ring_ok(g, t) || s > 1)) || (is_halo8(t) && !halo8_ok(g))) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
     if (g_force_split > 1 && g.act != ACT_GEGLU && g.K / (is_bf16 ? 64 : 32) >= g_force_split && !g.lora_a) {
         s = g_force_split;
         if (t >= 50) t = is_bf16 ? 14 : 1;
@@ -2793,6 +3058,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 #undef X
 #define X(id, bm, bn, wm, wn) case id: rc = launch_halo<bm, bn, wm, wn>(g, st); break;
         HALO_CFGS(X)
+#undef X
+#define X(id, bn, ns) case id: rc = launch_halo8<bn, ns>(g, st); break;
+        HALO8_CFGS(X)
 #undef X
 #define X(id, ks, nb) case id: rc = launch_ws<ks, nb>(g, st); break;
         WS_CFGS(X)

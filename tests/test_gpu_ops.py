@@ -252,6 +252,30 @@ def test_conv3x3_halo_kernel(tile, B, C1, C2, Cout, H, splitk):
     assert rel(y, ref) < TOL["bf16"]
 
 
+@pytest.mark.parametrize("tile,B,C1,C2,Cout,H,splitk", [
+    (46, 2, 64, 0, 320, 32, 1), (47, 1, 320, 0, 320, 16, 1), (48, 2, 128, 64, 160, 16, 1), (48, 1, 256, 0, 64, 32, 2),
+    (47, 1, 64, 64, 384, 32, 1), (48, 1, 64, 0, 160, 64, 1), (47, 1, 128, 0, 100, 32, 1), (46, 8, 320, 0, 320, 16, 2),
+    (48, 8, 640, 320, 320, 32, 1), (47, 8, 320, 320, 320, 32, 1), (48, 16, 64, 0, 320, 32, 1),
+])
+def test_conv3x3_halo_kernel_256_rows(tile, B, C1, C2, Cout, H, splitk):
+    """The eight-wave halo kernel (256-row tiles, one weight tile per phase for all of them, a ring of 2 / 3 / 4 weight stages
+    filled ahead with counted waits): widths 16 / 32 / 64, skip-concat source, split over channel chunks, ragged Cout (clamped
+    weight rows), one phase sequence longer than the ring and shorter tails, many more tiles than CUs; the same bits twice."""
+    from mrisr import ops
+    x1 = _rnd((B, C1, H, H), "bf16", 55)
+    x2 = _rnd((B, C2, H, H), "bf16", 56) if C2 else None
+    Cin = C1 + C2
+    w, b = _rnd((Cout, Cin, 3, 3), "f32", 57, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 58)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    ref = F.conv2d(xin, w.to(torch.bfloat16).float(), b, padding=1)
+    x1c, x2c, wc, bc = x1.cuda(), (x2.cuda() if x2 is not None else None), w.cuda(), b.cuda()
+    y = ops.conv3x3(x1c, wc, bc, x2=x2c, tile=tile, splitk=splitk)
+    assert rel(y, ref) < TOL["bf16"], rel(y, ref)
+    assert float((y.float().cpu() - ref).abs().max()) < 0.05 * float(ref.abs().max())
+    for _ in range(3):
+        assert torch.equal(y, ops.conv3x3(x1c, wc, bc, x2=x2c, tile=tile, splitk=splitk))
+
+
 @pytest.mark.parametrize("tile,M,N,K", [(50, 256, 320, 320), (50, 4096, 960, 320), (50, 64, 160, 320), (51, 320, 640, 320), (51, 1024, 128, 320),
                                         (52, 192, 640, 640), (52, 2048, 64, 640)])
 def test_linear_weight_stationary_kernel(tile, M, N, K):

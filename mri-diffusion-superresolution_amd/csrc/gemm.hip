@@ -560,6 +560,27 @@ __device__ __forceinline__ void bl16(__amdgpu_buffer_rsrc_t r, char* lds_wave_ba
 }
 #define BL_OOB 0x80000000u
 
+// ---- weight pre-touch -----------------------------------------------------------------------------------------------------------
+// In-model the weights of a layer are cold (HBM) when its GEMM starts, and the latency-bound GEMMs then pay an HBM round trip in every K step
+// in which some workgroup touches a weight tile first: with the weights pre-touched the GEMMs of one denoising step take 0.69 ms less
+// (profiles/r02y_weight_prefetch.log).  A side stream costs more than that in graph dependencies, so the kernel does it itself: right at
+// its start every workgroup DMAs ITS share of the whole weight matrix (1-KiB pieces, no use of the data) into a stage buffer that the first
+// real stage overwrites later.  All shares together request the matrix from HBM once, at full bandwidth, and the K loop's own fetches then
+// find it in the memory-side cache / L2.  The pieces are older than the first stage's DMA, so the first `vmcnt(0)` covers them.
+__device__ __forceinline__ void pretouch_weights(const __amdgpu_buffer_rsrc_t& rw, long long w_bytes, char* scratch, int wave, int lane) {
+    const int n_wg = (int)(gridDim.x * gridDim.y);
+    const int wg = (int)(blockIdx.x + blockIdx.y * gridDim.x);
+    const long long pieces = (w_bytes + 1023) >> 10;
+    const int per_wg = (int)((pieces + n_wg - 1) / n_wg);
+    const int per_wave = min((per_wg + 3) >> 2, 32);
+    const long long first = (long long)wg * per_wg + (long long)wave * per_wave;
+    for (int i = 0; i < per_wave; ++i) {
+        const long long pc = first + i;
+        const unsigned off = pc < pieces ? (unsigned)(pc << 10) + (unsigned)lane * 16u : BL_OOB;
+        bl16(rw, scratch + ((wave * 2 + (i & 1)) << 10), off, 0u);  // 8 KB of scratch: fits the smallest stage (BN = 64)
+    }
+}
+
 // NSTAGE = 2: double buffer, one drain (vmcnt(0)) + barrier per K tile; two workgroups share a CU and hide each other's
 // load latency.  Deeper rings with a counted vmcnt were tried twice (8-wave kernels, and 3-stage 4-wave variants on
 // in-range shapes) and lost every time (profiles/r01_gemm_sweep_incl_deep_stages.log, profiles/r01b_ws_sweep.log); note that
@@ -829,6 +850,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
 
     if constexpr (NSTAGE == 2) {
         if (kt_beg < kt_end) {
+            if (g.pretouch) pretouch_weights(rw, (long long)g.N * g.K * 2, smem + STAGE, wave, lane);
             stage(kt_beg, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1124,6 +1146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
 
     if (ch_beg < ch_end) {
         int cur = 0;
+        if (g.pretouch) pretouch_weights(rw, (long long)g.N * g.K * 2, wbase + WSTAGE, wave, lane);
         stage_w(ch_beg, 0, 0);
         for (int ch = ch_beg; ch < ch_end; ++ch) {
             stage_patch(ch);  // the previous chunk's last tap ended with a barrier: the patch buffer is free
@@ -3043,6 +3066,11 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
     if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;
     // split-K: the bf16 DMA kernels (tiled and halo) finish the reduction themselves
+    {   // cold-weight pre-touch: matrices of at least MRISR_PRETOUCH_MIN_KB (default 512; 0 ... 1024 measure the same); MRISR_PRETOUCH=0 turns it off
+        static const int on = [] { const char* e = getenv("MRISR_PRETOUCH"); return e ? atoi(e) : 1; }();
+        static const long long min_b = [] { const char* e = getenv("MRISR_PRETOUCH_MIN_KB"); return (e ? atoll(e) : 512ll) * 1024; }();
+        const_cast<GemmArgs&>(g).pretouch = (on && sizeof(T) == 2 && g.batch == 1 && (long long)g.N * g.K * 2 >= min_b) ? 1 : 0;
+    }
     const_cast<GemmArgs&>(g).sk_counters = nullptr;
     if (g.splitk > 1 && sizeof(T) == 2 && tile_reduces_in_kernel(tile)) {
         const long long ntiles = tile_count(tile, g) * (long long)g.batch;

@@ -103,7 +103,7 @@ struct GemmArgs {
     // per-tile arrival counters (zero between launches): the last split of a tile to arrive sums the slabs and runs the kernel's own
     // epilogue, so no separate reduce launch follows (set by launch_gemm for the bf16 DMA kernels; null = splitk_reduce_kernel)
     unsigned* sk_counters = nullptr;
-    int pretouch = 0;  // set by launch_gemm: the workgroups DMA-touch the whole weight matrix at kernel start (cold weights, see gemm.hip)
+    int pretouch = 0;  // set by launch_gemm (> 0: pieces per wave at most): the workgroups DMA-touch the whole weight matrix at kernel start (cold weights, see gemm.hip)
     // ---- epilogue ----
     float alpha = 1.0f;
     const float* bias = nullptr;    // [N] (GEGLU: interleaved like the weight rows)

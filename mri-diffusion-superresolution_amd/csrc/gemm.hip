@@ -1639,6 +1639,8 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
     // memory fetches every 128-byte line of a row twice as two 64-byte halves (k-steps 2t and 2t + 1): the load phase ran at
     // 3.8 TB/s of L2 traffic for 21 MB of rows (tools/probes/rp_probe.sh, flags 448).
     constexpr bool A_VIA_LDS = NW * 32 * K * 2 <= (FP8 && KS == 10 ? 81920 : 2 * CHUNK);
+    // (rows straight into registers: the buffers are free from the start - pre-touch the weights now, before the row fragments are live)
+    if (!A_VIA_LDS && g.pretouch > 0) pretouch_weights(rw, (long long)g.N * K * EW, smem + 2 * CHUNK - 8192, wave, lane, g.pretouch);
     bf16x8 af[MF][KS];
     if constexpr (A_VIA_LDS) {
         constexpr int ACPR = K / 8;                       // 16-byte chunks per row
@@ -1670,6 +1672,8 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
             for (int kk = 0; kk < KS; ++kk) af[j][kk] = rp_load16(ra, vo, (unsigned)(kk * 64));
         }
     }
+    // cold weights (pretouch_weights): the share lands in the last 8 KB of buffer 1 - behind the adapter rows, overwritten by chunk c_beg + 1
+    if (A_VIA_LDS && g.pretouch > 0) pretouch_weights(rw, (long long)g.N * K * EW, smem + 2 * CHUNK - 8192, wave, lane, g.pretouch);
     stage_w(c_beg, 0, true);
     if (LORA) {  // the adapters' A rows (R <= 16) borrow the front of buffer 1 until chunk c_beg + 1 is staged
         constexpr int LPIECES = 16 * CPR / 64;
@@ -2722,6 +2726,8 @@ static int launch_rp(int tile_id, const GemmArgs& g, hipStream_t st) {
     }
     ProfScope ps(prof_intern(pname), fl, by, st);
     const dim3 grid(panels, ysplit);
+    static const int pt_rp = [] { const char* e = getenv("MRISR_PRETOUCH_RP"); return e ? atoi(e) : 1; }();
+    if (!pt_rp) const_cast<GemmArgs&>(g).pretouch = 0;
     const bool lora = g.lora_a != nullptr;
     if (!g.bias) {  // the kernel loads its chunk's bias unconditionally (straight-line code around the wait counts): zeros
         MRISR_REQUIRE((size_t)g.N * sizeof(float) <= kZeroPageBytes, "row-panel kernel without bias: N beyond the zero page");

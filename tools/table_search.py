@@ -19,7 +19,7 @@ from mrisr import _lib as L  # noqa: E402
 from mrisr import params as P  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 480.0
-table_path = os.path.join(ROOT, "profiles", "r01_tune_cache.tsv")
+table_path = os.path.join(ROOT, "profiles", "r02_tune_cache.tsv")
 os.environ["MRISR_TUNE_CACHE"] = table_path
 entries = []
 for line in open(table_path):
@@ -29,11 +29,11 @@ dev = torch.device("cuda", 0)
 cfg = mrisr.UNetConfig()
 sd = P.random_state_dict(P.unet_param_shapes(cfg), bench.SEED, dev)
 sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), bench.SEED + 3, dev))
-unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
+unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, lora_fused=True)
 unet.load_state_dict(sd)
 sched = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
 sched.set_timesteps(50)
-lr_lat, ctx, noise = bench.synthetic_batch(32, dev, 0)
+lr_lat, ctx, noise, _hr = bench.synthetic_batch(32, dev, 0)
 x_T = (lr_lat + noise).contiguous()
 lib = L.lib()
 
@@ -68,7 +68,9 @@ for i in order:
     M, N, K, f = dims(key)
     conv, geglu = f[3] == "c1", f[8] == "a3"
     cands = []
-    for t in (14, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44):
+    for t in (14, 16, 17, 18, 25, 26, 28, 41, 42, 43, 44, 60, 61, 64, 65):
+        if t >= 60 and (conv or K not in (320, 640)):
+            continue
         if t >= 40 and not (conv and f[4] == "s1" and f[5] == "u0"):
             continue
         if geglu and t in (25, 26):

@@ -1687,6 +1687,21 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
             if (piece < LPIECES) bl16(rl, smem + CHUNK + piece * 1024, vo, 0u);
         }
     }
+    // LayerNorm: gamma | beta (f32) into LDS by DMA, between the adapter rows and the pre-touch scratch of buffer 1.  The apply loop used to load
+    // them from global memory k-step by k-step - KS serialized round trips, 7-14 us per launch, most of the prologue's cost.
+    constexpr int LNP = (K * 4 + 1023) / 1024;         // 1-KiB pieces per vector
+    constexpr int GB_OFF = 2 * CHUNK - 8192 - 6144;    // 6 KB: [gamma LNP KB][beta LNP KB]
+    static_assert(2 * LNP <= 6 && GB_OFF >= CHUNK + 16 * K * EW, "LayerNorm vectors fit between the adapter rows and the scratch");
+    if (PRO == 1) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(g.ln_gamma, (unsigned)(K * 4));
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(g.ln_beta, (unsigned)(K * 4));
+#pragma unroll
+        for (int p = 0; p < (2 * LNP + NW - 1) / NW; ++p) {
+            const int piece = p * NW + wave;
+            if (piece < LNP) bl16(rg, smem + GB_OFF + piece * 1024, (unsigned)(piece * 1024 + lane * 16), 0u);
+            else if (piece < 2 * LNP) bl16(rb, smem + GB_OFF + piece * 1024, (unsigned)((piece - LNP) * 1024 + lane * 16), 0u);
+        }
+    }
 
     if (PRO == 1) {
         // LayerNorm over the K extent of each resident row: a row's K values live in the 4 lanes {fr + 16 fg'}.  ONE statistics pass
@@ -1714,8 +1729,10 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
                 af[j][kk] = __builtin_bit_cast(bf16x8, w);
             }
         }
-        const float* gp = g.ln_gamma + fg * 8;
-        const float* bp = g.ln_beta + fg * 8;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // gamma / beta (every wave's pieces), and with them chunk c_beg: all due now anyway
+        __syncthreads();
+        const float* gp = reinterpret_cast<const float*>(smem + GB_OFF) + fg * 8;
+        const float* bp = reinterpret_cast<const float*>(smem + GB_OFF + LNP * 1024) + fg * 8;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {  // k outer: this k-step's gamma / beta serve both row fragments
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + kk * 32), g1 = *reinterpret_cast<const f32x4*>(gp + kk * 32 + 4);
@@ -2105,6 +2122,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
         __syncthreads();
     }
     stage(0, 0, true);
+    // LayerNorm vectors into LDS (W2 buffer 1, free until the loop's first barrier): see the row-panel kernel
+    constexpr int GP = (K * 4 + 1023) / 1024;
+    constexpr int GB_OFF = W2BASE + CH2;
+    {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.ln_gamma, (unsigned)(K * 4));
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.ln_beta, (unsigned)(K * 4));
+        if (wave < GP) bl16(rg, smem + GB_OFF + wave * 1024, (unsigned)(wave * 1024 + lane * 16), 0u);
+        else if (wave < 2 * GP) bl16(rb, smem + GB_OFF + wave * 1024, (unsigned)((wave - GP) * 1024 + lane * 16), 0u);
+        static_assert(2 * GP <= 4, "one piece per wave");
+    }
     {
         float mean[MF], rstd[MF];
 #pragma unroll
@@ -2127,8 +2154,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
                 af[j][kk] = __builtin_bit_cast(bf16x8, w);
             }
         }
-        const float* gp = a.ln_gamma + fg * 8;
-        const float* bp = a.ln_beta + fg * 8;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* gp = reinterpret_cast<const float*>(smem + GB_OFF) + fg * 8;
+        const float* bp = reinterpret_cast<const float*>(smem + GB_OFF + GP * 1024) + fg * 8;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + kk * 32), g1 = *reinterpret_cast<const f32x4*>(gp + kk * 32 + 4);

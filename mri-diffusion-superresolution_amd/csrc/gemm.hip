@@ -491,28 +491,43 @@ __device__ __forceinline__ void copy_out_tile(const GemmArgs& g, const bf16* oti
     constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
     bf16* out = reinterpret_cast<bf16*>(g.out) + (size_t)z * g.o_bs;
     const bf16* res = add_resid ? reinterpret_cast<const bf16*>(g.resid) + (size_t)z * g.o_bs : nullptr;
-    for (int idx = threadIdx.x; idx < BM * CPR; idx += NT) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int m = m0 + row, n = n0 + ch * 8;
-        if (m >= g.M || n >= g.N) continue;
-        const bf16* src = otile + row * pitch + ch * 8;
-        bf16* dst = out + (size_t)m * g.ldo + n;
-        if (n + 8 <= g.N) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
-            if (res) {  // residual added here, read as whole rows too (may alias dst: same thread reads then writes)
-                const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + (size_t)m * g.ldr + n);
+    // Residual pieces of a BATCH of rows are loaded first, then added and stored: the one-piece-at-a-time loop (load, add, store; the store may alias
+    // the next load as far as the compiler knows) was a chain of dependent L2 round trips - 5 to 10 per workgroup.  A lane only ever reads the addresses
+    // it writes itself, so reading ahead of its own stores is safe when the residual aliases the output.
+    constexpr int TOTAL = BM * CPR, IT = (TOTAL + NT - 1) / NT, BATCH = IT < 5 ? IT : 5;
+    for (int it0 = 0; it0 < IT; it0 += BATCH) {
+        bf16x8 rv[BATCH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
-            }
-            *reinterpret_cast<bf16x8*>(dst) = v;
-        } else {
-            bf16x4 v = *reinterpret_cast<const bf16x4*>(src);  // N % 8 == 4 tail
-            if (res) {
-                const bf16x4 r = *reinterpret_cast<const bf16x4*>(res + (size_t)m * g.ldr + n);
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = (int)threadIdx.x + (it0 + u) * NT;
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (res && idx < TOTAL && m < g.M && n + 8 <= g.N) rv[u] = *reinterpret_cast<const bf16x8*>(res + (size_t)m * g.ldr + n);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = (int)threadIdx.x + (it0 + u) * NT;
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (idx >= TOTAL || m >= g.M || n >= g.N) continue;
+            const bf16* src = otile + row * pitch + ch * 8;
+            bf16* dst = out + (size_t)m * g.ldo + n;
+            if (n + 8 <= g.N) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+                if (res) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[u][e]);
+                }
+                *reinterpret_cast<bf16x8*>(dst) = v;
+            } else {
+                bf16x4 v = *reinterpret_cast<const bf16x4*>(src);  // N % 8 == 4 tail
+                if (res) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(res + (size_t)m * g.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+                }
+                *reinterpret_cast<bf16x4*>(dst) = v;
             }
-            *reinterpret_cast<bf16x4*>(dst) = v;
         }
     }
 }
@@ -1995,6 +2010,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
                 if (g.dbg & 512) { if (v[0] == (bf16)1.2345e30f) *reinterpret_cast<bf16x8*>(base) = v; continue; }  // probe: no global store
                 if (!heads) {
                     if (has_resid) {  // residual read as whole rows too (may alias the output: same lane reads then writes)
+                        // (batching these loads ahead of the adds, as copy_out_tile does, spills here: the row fragments are live)
                         const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(g.resid) + (size_t)m * g.ldr + n);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
@@ -2278,17 +2294,30 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
     constexpr int CPRO = N2 / 8;
     T* ob = reinterpret_cast<T*>(a.out);
     const T* rb = reinterpret_cast<const T*>(a.resid);
-    for (int idx = lane; idx < 32 * CPRO; idx += 64) {
-        const int row = idx / CPRO, ch = idx - row * CPRO;
-        const int m = m0 + wave * 32 + row;
-        if (m >= a.M) continue;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(wt + row * OP + ch * 8);
-        if (rb) {
-            const bf16x8 r = *reinterpret_cast<const bf16x8*>(rb + (size_t)m * a.ldr + ch * 8);
+    constexpr int ITO = 32 * CPRO / 64, OB = 5;  // 20 pieces per lane, residual pieces five at a time ahead of their adds (see copy_out_tile)
+    static_assert(32 * CPRO % 64 == 0 && ITO % OB == 0, "whole batches");
+    for (int it0 = 0; it0 < ITO; it0 += OB) {
+        bf16x8 rv[OB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)r[e]);
+        for (int u = 0; u < OB; ++u) {
+            const int idx = (it0 + u) * 64 + lane;
+            const int row = idx / CPRO, ch = idx - row * CPRO;
+            const int m = m0 + wave * 32 + row;
+            if (rb && m < a.M) rv[u] = *reinterpret_cast<const bf16x8*>(rb + (size_t)m * a.ldr + ch * 8);
         }
-        *reinterpret_cast<bf16x8*>(ob + (size_t)m * a.ldo + ch * 8) = v;
+#pragma unroll
+        for (int u = 0; u < OB; ++u) {
+            const int idx = (it0 + u) * 64 + lane;
+            const int row = idx / CPRO, ch = idx - row * CPRO;
+            const int m = m0 + wave * 32 + row;
+            if (m >= a.M) continue;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(wt + row * OP + ch * 8);
+            if (rb) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[u][e]);
+            }
+            *reinterpret_cast<bf16x8*>(ob + (size_t)m * a.ldo + ch * 8) = v;
+        }
     }
 }
 

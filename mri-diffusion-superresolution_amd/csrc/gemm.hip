@@ -1168,6 +1168,20 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(const GemmArgs g) {
             stage_patch(ch);  // the previous chunk's last tap ended with a barrier: the patch buffer is free
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (g.dbg & 1024) {
+                // probe (MRISR_GEMM_FLAGS=1024; results are wrong): what GroupNorm + SiLU applied in the CONSUMER would cost - one LDS -> VALU -> LDS pass over
+                // the staged patch per 64-channel chunk (scale / shift per channel from LDS-resident vectors would come on top)
+                for (int t = tid; t < npix * 8; t += 256) {
+                    bf16x8 v = *reinterpret_cast<bf16x8*>(patch + t * 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e] * 1.0009765625f + 0.03125f;
+                        v[e] = (bf16)(f / (1.0f + __expf(-f)));
+                    }
+                    *reinterpret_cast<bf16x8*>(patch + t * 16) = v;
+                }
+                __syncthreads();
+            }
             for (int tap = 0; tap < 9; ++tap) {
                 if (tap + 1 < 9) stage_w(ch, tap + 1, cur ^ 1);
                 else if (ch + 1 < ch_end) stage_w(ch + 1, 0, cur ^ 1);

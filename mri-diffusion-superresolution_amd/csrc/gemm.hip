@@ -2399,11 +2399,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
         const int n = (int)(i - (long long)m * nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         const float* p = g.partial + (size_t)z * g.splitk * (size_t)g.M * g.N + (size_t)m * g.N + n;
+        // the plain row-output form (every split conv / linear of the models): bias, time-embedding row and residual are requested BEFORE the slabs are summed -
+        // inside epilogue4 each of them is one more dependent round trip behind the slab loads
+        const bool fast = g.out_mode == OUT_ROWS && !g.lora_z && g.heads == 1 && g.batch == 1;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f}, t4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (fast) {
+            if (g.bias) load4<float>(g.bias + n, b4);
+            if (g.rowvec) load4<float>(g.rowvec + (size_t)(m / g.rowvec_div) * g.rowvec_ld + n, t4);
+            if (g.resid) load4<T>(reinterpret_cast<const T*>(g.resid) + (size_t)m * g.ldr + n, r4);
+        }
         for (int s = 0; s < g.splitk; ++s) {
             float t[4];
             load4<float>(p + (size_t)s * g.M * g.N, t);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += t[r];
+        }
+        if (fast) {  // the same operations in the same order as epilogue4
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * g.alpha + b4[r];
+            if (g.rowvec) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += t4[r];
+            }
+            if (g.act == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (g.act == ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            if (g.resid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += r4[r];
+            }
+            store4<T>(reinterpret_cast<T*>(g.out) + (size_t)m * g.ldo + n, v);
+            continue;
         }
         epilogue4<T>(g, z, m, n, v, nullptr, nullptr, nullptr, false, /*mfma_lanes=*/false);
     }

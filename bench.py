@@ -8,6 +8,7 @@ independent slices, so there is NO data-path collective (weak scaling) - torch.d
 the barrier and the max-over-ranks time.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...          (no launcher: starts its own N children, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -120,6 +121,51 @@ def cpu_baseline(state_dict_cpu, cfg_oracle, threads, x_T, ctx, n_steps):
             "sample_steps_per_s": B * n_steps / dt}, traj[-1]
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process has made NO GPU call (importing torch
+    does not initialise HIP), so it may start N fresh children - one per GPU, the same environment torchrun would give them
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) - relay their output (only rank 0 prints the JSON line) and
+    exit with the worst child's code.  Children are separate processes (no exec from a GPU-initialised process anywhere)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        log(f"self-launch: ranks failed (rank, rc): {bad}")
+    return max(((128 - rc) if rc < 0 else rc) for rc in rcs)  # a child killed by signal s counts as 128 + s
+
+
+def launcher_selftest(world, rank):
+    """`--launcher-selftest` (CPU, gloo): the rendezvous, the barrier and the max-over-ranks reduce of the bench contract
+    without a model - what tests/test_dist_cpu.py drives through the self-launcher."""
+    import torch.distributed as dist
+    from mrisr import dist as mdist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    slowest = mdist.max_over_ranks(1.0 + rank)
+    seen = mdist.sum_over_ranks(1.0)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(seen), "slowest": slowest,
+                          "scaling": "weak"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,12 +179,18 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=N_DDIM, help="(profiling only) fewer denoising steps; the metric needs 50")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
                     help="per-kernel-class HBM bytes per launch from tools/collect_traffic.sh (PMC passes of this command)")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.launcher_selftest:
+        return launcher_selftest(world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

@@ -408,12 +408,11 @@ struct Runner {
                 skips->push_back(x);
             }
             if (!has_attn && ib < n_intra) {
-                // attention-free block: the adapter feature is added after the block returned, so the skips pushed
-                // above must not see it -> work on a copy
-                Act y = new_act(x.B, x.H, x.W, x.C);
-                if (!y.p) return 7;
-                if (!dry) MRISR_CHECK_HIP(hipMemcpyAsync(y.p, x.p, x.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
-                x = y;
+                // attention-free block: diffusers adds the adapter feature AFTER the block returned, but IN PLACE
+                // (`sample += down_intrablock_additional_residuals.pop(0)`, unet_2d_condition.py forward) on the very
+                // tensor DownBlock2D also returned as res_samples[-1] - so the LAST skip pushed above carries the
+                // feature (as in the original TencentARC loop, which adds before hs.append(h)); the earlier skips of
+                // the block do not.  x shares its buffer with skips->back(): add in place.
                 TRY(add_external(x, intrablock[ib++]));
             }
         }

@@ -737,11 +737,8 @@ struct Trainer : Runner<T> {
                 skips.push_back(x);
             }
             if (!has_attn && ib < n_intra) {
-                Act y = new_act(x.B, x.H, x.W, x.C);
-                if (!y.p) return 7;
-                if (!dry) MRISR_CHECK_HIP(hipMemcpyAsync(y.p, x.p, x.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
-                TRY(pass_grad(y, x));
-                x = y;
+                // in place on the last skip (see Runner::encoder): d(feature) = d(x) with x's slot collecting the mid
+                // block's AND the decoder's (skip) contributions
                 TRY(R::add_external(x, intrablock[ib]));
                 TRY(export_feature_grad(x, ib++));
             }

@@ -58,11 +58,13 @@ def res_srdiff_sample(unet: Callable, controlnet: Optional[Callable], lr_latents
     """The loop of res_srdiff.py:58-96 with all noise supplied by the caller.
     Returns the state BEFORE every step plus the final state (len(timesteps)+1 tensors)."""
     ts = [int(t) for t in timesteps]
-    x = res_shift_forward(lr_latents, lr_latents, torch.tensor(ts[0]), alphas_cumprod, init_noise)
+    dev = lr_latents.device  # the reference keeps timesteps / alphas_cumprod on accelerator.device (:53-60): 0-dim device t
+    alphas_cumprod = alphas_cumprod.to(dev)
+    x = res_shift_forward(lr_latents, lr_latents, torch.tensor(ts[0], device=dev), alphas_cumprod, init_noise)
     traj = [x]
     k = 0
     for i, t in enumerate(ts):
-        tt = torch.tensor(t, dtype=torch.int64)
+        tt = torch.tensor(t, dtype=torch.int64, device=dev)
         down = mid = None
         if controlnet is not None:
             down, mid = controlnet(x, tt, encoder_hidden_states=ctx, controlnet_cond=control_image,

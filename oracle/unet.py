@@ -359,8 +359,10 @@ def time_embed(p: Params, t: Tensor, batch: int, cfg: UNetConfig, dtype) -> Tens
 
 
 def _encoder(p: Params, cfg: UNetConfig, x: Tensor, emb: Tensor, ctx: Tensor, lora_scale: float,
-             intrablock: Optional[List[Tensor]] = None) -> Tuple[Tensor, List[Tensor]]:
-    """Down path + mid block.  ``x`` is already conv_in(sample) (+ ControlNet cond embedding)."""
+             intrablock: Optional[List[Tensor]] = None, last_skip_inplace: bool = True) -> Tuple[Tensor, List[Tensor]]:
+    """Down path (no mid block).  ``x`` is already conv_in(sample) (+ ControlNet cond embedding).
+    ``last_skip_inplace=False`` is a TEST hook only: the out-of-place reading of the attention-free hand-off (rounds 1-2),
+    kept so that tests can show the product follows the in-place one."""
     skips = [x]
     intrablock = list(intrablock) if intrablock is not None else []
     for i in range(cfg.num_levels):
@@ -376,7 +378,16 @@ def _encoder(p: Params, cfg: UNetConfig, x: Tensor, emb: Tensor, ctx: Tensor, lo
             x = conv(p, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
             skips.append(x)
         if not has_attn and intrablock:
-            x = x + intrablock.pop(0)  # attention-free block: added after the block returned
+            # attention-free block: diffusers' UNet2DConditionModel.forward does
+            #     sample, res_samples = downsample_block(hidden_states=sample, temb=emb)
+            #     sample += down_intrablock_additional_residuals.pop(0)
+            # and DownBlock2D.forward returns (hidden_states, output_states) with output_states[-1] IS hidden_states
+            # (the last resnet's output, or the downsampler's), so the in-place add also lands in res_samples[-1]:
+            # the block's LAST skip carries the feature, its earlier skips do not.  Same order as the original
+            # TencentARC T2I-Adapter loop (h = h + feature before hs.append(h)).
+            x = x + intrablock.pop(0)
+            if last_skip_inplace:
+                skips[-1] = x
     return x, skips
 
 
@@ -390,13 +401,14 @@ def unet_forward(p: Params, cfg: UNetConfig, sample: Tensor, timestep, encoder_h
                  down_block_additional_residuals: Optional[Sequence[Tensor]] = None,
                  mid_block_additional_residual: Optional[Tensor] = None,
                  down_intrablock_additional_residuals: Optional[Sequence[Tensor]] = None,
-                 lora_scale: float = 1.0) -> Tensor:
-    """eps_hat = UNet(x_t, t, ctx [, ControlNet residuals] [, T2I-Adapter residuals]).  App. A.1."""
+                 lora_scale: float = 1.0, _adapter_last_skip_inplace: bool = True) -> Tensor:
+    """eps_hat = UNet(x_t, t, ctx [, ControlNet residuals] [, T2I-Adapter residuals]).  App. A.1.
+    (``_adapter_last_skip_inplace``: test hook, see ``_encoder``.)"""
     B = sample.shape[0]
     ctx = encoder_hidden_states
     emb = time_embed(p, timestep, B, cfg, sample.dtype)
     x = conv(p, "conv_in", sample)
-    x, skips = _encoder(p, cfg, x, emb, ctx, lora_scale, down_intrablock_additional_residuals)
+    x, skips = _encoder(p, cfg, x, emb, ctx, lora_scale, down_intrablock_additional_residuals, _adapter_last_skip_inplace)
     if down_block_additional_residuals is not None:
         skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
     x = _mid(p, cfg, x, emb, ctx, lora_scale)

@@ -265,3 +265,25 @@ def test_bucketed_reducer_validates_and_is_identity_without_group():
         md.BucketedReducer(v, [(0, 4), (5, 10)])   # gap
     with pytest.raises(ValueError):
         md.BucketedReducer(v, [(0, 10)], mode="ring")
+
+
+def test_bench_self_launches_its_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no launcher (WORLD_SIZE unset - how the driver invokes the bench): the parent, which makes no
+    GPU call, starts two children with torchrun's environment, relays rank 0's single JSON line and exits with the worst child's
+    code.  CPU stand-in for the model (`--launcher-selftest`: gloo rendezvous + the contract's barrier / max-over-ranks)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # (gloo itself prints a connection note on stdout)
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["slowest"] == 2.0
+    # a launcher/flag mismatch is a clean error, not an assert trace
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -263,6 +263,8 @@ def test_adapter_gradients_match_autograd(tiny, dt, tol):
     app = {k: v.clone().requires_grad_(True) for k, v in ap.items()}
     with torch.enable_grad():
         feats = oa.adapter_forward(app, acfg, cond)
+        for f in feats:
+            f.retain_grad()
         pred = ou.unet_forward({**up, **lp}, cfg, x, t, ctx, down_intrablock_additional_residuals=feats, lora_scale=1.0)
         loss_ref = torch.nn.functional.mse_loss(pred, tgt)
         loss_ref.backward()
@@ -280,6 +282,10 @@ def test_adapter_gradients_match_autograd(tiny, dt, tol):
     fg = atr.new_feature_grads()
     loss = ltr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), down_intrablock_additional_residuals=dfeats, feature_grads=fg)
     assert abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < tol
+    # d(loss)/d(feature i): feature 3's gradient is the mid block's PLUS the decoder's through skip 11 (the in-place add
+    # of diffusers' attention-free hand-off lands in res_samples[-1])
+    for i, (gf, f) in enumerate(zip(fg, feats)):
+        assert rel(gf, f.grad) < tol, (i, rel(gf, f.grad))
     atr.backward(fg)
     flat_ref = torch.cat([app[k].grad.reshape(-1) for k, _, _ in atr.layout])
     assert rel(atr.grad, flat_ref) < tol, rel(atr.grad, flat_ref)

@@ -195,6 +195,18 @@ def test_adapter_matches_reference_golden_and_feeds_unet(tiny, golden_dir, dt, t
     net.load_state_dict(up)
     out = net(x.cuda(), 77, encoder_hidden_states=ctx.cuda(), down_intrablock_additional_residuals=[f.cuda() for f in fo]).sample
     assert rel(out, ref) < (1e-3 if dt == "f32" else 5e-2)
+    # the LAST skip carries feature 3 (diffusers' in-place `sample +=` on res_samples[-1]): with a strong feature 3 the
+    # product follows the in-place oracle and is far from the out-of-place reading (skip 11 without the feature)
+    big = [f.clone() for f in fo]
+    big[3] = big[3] * 32.0
+    ref_in = ou.unet_forward(up, cfg, x, torch.tensor(77), ctx, down_intrablock_additional_residuals=[f.clone() for f in big])
+    ref_out = ou.unet_forward(up, cfg, x, torch.tensor(77), ctx, down_intrablock_additional_residuals=[f.clone() for f in big],
+                              _adapter_last_skip_inplace=False)
+    out = net(x.cuda(), 77, encoder_hidden_states=ctx.cuda(), down_intrablock_additional_residuals=[f.cuda() for f in big]).sample
+    tl = 1e-3 if dt == "f32" else 5e-2
+    assert rel(out, ref_in) < tl
+    if dt == "f32":  # the two readings differ by 2.3e-2 here: distinguishable at the f32 tolerance, not at the bf16 one
+        assert rel(ref_out, ref_in) > 1e-2 and rel(out, ref_out) > 1e-2
 
 
 def test_forward_shift_matches_reference_golden(golden_dir):
@@ -252,6 +264,46 @@ def test_log_validation_matches_reference_trajectory(tiny, golden_dir, tag):
     W = panel.shape[1] // 3
     small = panel[:, W:2 * W][::8, ::8, 0]
     assert np.abs(small.astype(int) - g["gen_panel_small"].astype(int)).max() <= 1
+
+
+def test_reference_eager_loop_over_product_models_matches_reference_trajectory(tiny, golden_dir):
+    """the reference's OWN per-step loop (res_srdiff.py:63-96; here its pinned restatement
+    oracle.sampler.res_srdiff_sample, which is checked against the same golden on the CPU) keeps working when it is handed the
+    product's duck-typed models: a 0-dim device `t`, `return_dict=False` -> (tuple of 12 residuals, mid), `.sample`, torch
+    arithmetic on the device between the calls.  Every state of the reference's N=5 run."""
+    import mrisr
+    from oracle import sampler as osa
+    g = np.load(os.path.join(golden_dir, "log_validation_n5.npz"))
+    cfg, up, lora, cp = tiny
+    unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=4, lora_alpha=4)
+    unet.load_state_dict({**up, **lora})
+    cnet = mrisr.ControlNetModel(cfg, compute_dtype="f32")
+    cnet.load_state_dict(cp)
+    gen = torch.Generator().manual_seed(201)
+    base = torch.randn((1, 1, 32, 32), generator=gen)
+    hr = torch.nn.functional.interpolate(base, size=(512, 512), mode="bicubic", align_corners=False).clamp(-1, 1)
+    lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 4), scale_factor=4.0, mode="bilinear")
+    ctx = torch.randn((1, 77, cfg.cross_attention_dim), generator=torch.Generator().manual_seed(301)).cuda()
+    lr_lat = (torch.nn.functional.avg_pool2d(lr, 8).repeat(1, 4, 1, 1) * 0.18215).cuda()
+    cond = mrisr.prepare_condition_image(lr.cuda())
+    torch.manual_seed(int(g["seed"]))
+    init_noise = torch.randn(lr_lat.shape).cuda()
+    step_noise = [torch.randn(lr_lat.shape).cuda() for _ in range(4)]
+    sched = mrisr.DDPMScheduler(timestep_spacing="leading", steps_offset=1)
+    sched.set_timesteps(5, device="cuda")
+    seen = []
+
+    def unet_spy(x, t, **kw):  # what the loop hands over: 0-dim int64 device t, a tuple of 12 device residuals + mid
+        seen.append((t.ndim, t.device.type, t.dtype, len(kw["down_block_additional_residuals"]),
+                     tuple(kw["mid_block_additional_residual"].shape)))
+        return unet(x, t, **kw)
+
+    traj = osa.res_srdiff_sample(unet_spy, cnet, lr_lat, ctx[0:1], cond, sched.timesteps, sched.alphas_cumprod, init_noise, step_noise)
+    assert len(traj) == 6 and all(s == (0, "cuda", torch.int64, 12, (1, cfg.block_out_channels[-1], 1, 1)) for s in seen), seen
+    for k, x in enumerate(traj):
+        assert x.is_cuda and x.dtype == torch.float32
+        r = rel(x, torch.from_numpy(g["states"][k]))
+        assert r < 1e-3, (k, r)  # north_star: 1e-3 rel f32
 
 
 def test_sampler_trajectory_states_and_graph_equals_eager(tiny, golden_dir):

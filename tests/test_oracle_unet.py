@@ -134,6 +134,36 @@ def test_controlnet_shapes_and_residual_injection():
     assert all(float(d.abs().max()) == 0 for d in down0) and float(mid0.abs().max()) == 0
 
 
+def test_adapter_feature_of_the_attention_free_block_lands_in_its_last_skip():
+    """diffusers: `sample += down_intrablock_additional_residuals.pop(0)` is IN PLACE on the tensor DownBlock2D also returned
+    as res_samples[-1] -> the last of the 12 skips carries feature 3, skip 10 (the block's first resnet) does not; features
+    0-2 (cross-attention blocks) land in the skip of the block's last (resnet, attention) pair, not in the downsampler's."""
+    cfg = ou.TINY
+    up = ou.init_unet_params(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, cfg.block_out_channels[0], 8, 8), generator=g)
+    ctx = torch.randn((1, 77, cfg.cross_attention_dim), generator=g)
+    emb = ou.time_embed(up, torch.tensor(7), 1, cfg, x.dtype)
+    feats = [torch.randn((1, c, 8 >> i, 8 >> i), generator=g) for i, c in enumerate(cfg.block_out_channels)]
+    feats[3] = torch.randn((1, cfg.block_out_channels[3], 1, 1), generator=g)  # level 3 runs at the level-2 downsampler's size
+    x0, s0 = ou._encoder(up, cfg, x, emb, ctx, 1.0)
+    x1, s1 = ou._encoder(up, cfg, x, emb, ctx, 1.0, [f.clone() for f in feats])
+    assert len(s0) == len(s1) == 12
+    # level 0: skips 0 (conv_in), 1, 2 (resnet+attn pairs), 3 (downsampler)
+    assert torch.equal(s1[0], s0[0]) and torch.equal(s1[1], s0[1])
+    assert torch.allclose(s1[2], s0[2] + feats[0], atol=1e-6)
+    # a feature of level 3 alone: only the LAST skip and the mid input move, by exactly the feature
+    x3, s3 = ou._encoder(up, cfg, x, emb, ctx, 1.0, None)
+    only3 = [torch.zeros_like(f) for f in feats[:3]] + [feats[3]]
+    x4, s4 = ou._encoder(up, cfg, x, emb, ctx, 1.0, only3)
+    for k in range(11):
+        assert torch.equal(s4[k], s3[k]), k
+    assert torch.allclose(s4[11], s3[11] + feats[3], atol=1e-6) and torch.equal(x4, s4[11])
+    # the out-of-place reading (test hook) leaves skip 11 alone - that is what rounds 1-2 computed
+    x5, s5 = ou._encoder(up, cfg, x, emb, ctx, 1.0, only3, last_skip_inplace=False)
+    assert torch.equal(s5[11], s3[11]) and torch.equal(x5, x4)
+
+
 def test_time_embedding_layout():
     e = ou.timestep_embedding(torch.tensor([0, 1, 999]), 320)
     assert e.shape == (3, 320)

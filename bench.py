@@ -293,6 +293,8 @@ def main():
             tj = json.load(open(args.traffic_json))
             if dom_name in tj:
                 roof["traffic"] = tj[dom_name]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command (tools/collect_traffic.sh), NOT collected in this run")
                 roof["alg_bytes_per_launch"] = d["bytes"] / d["launches"]
         except (OSError, ValueError):
             pass
@@ -307,6 +309,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[1]: 256x256 1-ch synthetic MRI slices -> 4x32x32 latents, SD-1.5-size UNet "
                                "(859.5M params, random init) + rank-4 LoRA, 50-step DDIM, bs=32 per GPU",
+                   "weights": "random-init (no checkpoints offline); the fidelity block is numerical agreement with the CPU oracle only, "
+                              "it says nothing about image quality",
                    "slices_per_gpu_per_step": B, "ddim_steps": args.ddim_steps, "parallelism": f"slice-sharded x{world} (no collective)",
                    "lora": "merged" if args.lora_merged else "explicit adapters, down-projection + rank-r update inside the projection GEMMs",
                    "tile_table": os.environ.get("MRISR_TUNE_CACHE", "online autotune"), "hipgraph": not args.no_graph},

@@ -18,7 +18,8 @@ void mrisr_debug_force_split(int splitk);
 void mrisr_debug_force_tile(int tile);
 void mrisr_debug_prefer_tile(int tile);
 /* bit flags: 8 = rank-4 LoRA up-projection in the scalar epilogue instead of on the matrix cores; 16 = head-major outputs
- * stored straight from the accumulator layout instead of through LDS */
+ * stored straight from the accumulator layout instead of through LDS; 2048 = every GEMM workgroup fills its LDS allocation with
+ * 0xFF bytes (NaN) before its first LDS-DMA, so that a read that runs ahead of its DMA cannot return plausible stale data */
 void mrisr_debug_gemm_flags(int flags);
 /* cost-model efficiency of one tile id (only used when the autotuner is off) */
 void mrisr_debug_set_tile_eff(int tile, double eff);

@@ -14,3 +14,5 @@ from .train import AdapterTrainer, joint_step, joint_step_overlapped  # noqa: F4
 from .dist import BucketedReducer  # noqa: F401
 from .datasets import (FastMRILazyDataset, SliceDataset, gaussian_blur, get_data_dicts_artificial,  # noqa: F401
                        pad_or_center_crop, resize_slices, simulate_low_field)
+from .prompts import compute_embeddings_sd1x5, encode_prompt_sd1x5, get_fixed_prompt_embeds  # noqa: F401
+from .config import TrainConfig, log_configs  # noqa: F401

@@ -171,7 +171,53 @@ def gen_adapter():
     print("adapter ok", missing, [tuple(f.shape) for f in feats])
 
 
+def gen_prompts():
+    """the reference's prompt producers (utils.py:117-160, res_srdiff.py:125-130) driven with the stub tokenizer /
+    text encoder of oracle/prompt_stubs.py, and the reference's log_configs (utils.py:37-71) on the notebook's own config cell."""
+    import json
+    import random
+
+    import yaml
+    from src.adapters import utils as ref_utils  # (reference)
+
+    from oracle.prompt_stubs import StubTextEncoder, StubTokenizer
+
+    sys.path.insert(0, os.path.join(ROOT, "mri-diffusion-superresolution_amd"))
+    from mrisr.config import TrainConfig
+
+    tok, enc = StubTokenizer(), StubTextEncoder(dim=768, seed=501)
+    fixed = ref.get_fixed_prompt_embeds(tok, enc, Accel())
+    batch = {"txt": ["high quality MRI scan, T2w brain slice, 3T", ["axial T1w", "sagittal T1w", "coronal T1w"],
+                     np.array(["low field 64mT", "high field 3T"]), "high quality mri scan", ["a", "b"], "medical mri scan"]}
+    outs = {}
+    for tag, p_empty, is_train, seed in (("train", 0.5, True, 7), ("eval", 0.0, False, 8), ("dropall", 1.0, True, 9)):
+        tok.seen.clear()
+        random.seed(seed)
+        e = ref_utils.compute_embeddings_sd1x5(batch, p_empty, [enc], [tok], torch.device("cpu"), is_train=is_train)
+        assert set(e) == {"prompt_embeds"}
+        pe = e["prompt_embeds"]
+        assert tuple(pe.shape) == (6, 77, 768)
+        outs[f"{tag}_embeds_small"] = pe[:, ::4, ::24].numpy().copy()  # the stubs are deterministic: a sample + checksums pin it
+        outs[f"{tag}_embeds_abs_sum"] = np.array(float(pe.double().abs().sum()))
+        outs[f"{tag}_embeds_sha256"] = np.array(hashlib.sha256(pe.numpy().tobytes()).hexdigest())
+        outs[f"{tag}_captions"] = np.array(json.dumps(tok.seen[-1]))
+        outs[f"{tag}_args"] = np.array(json.dumps({"proportion_empty_prompts": p_empty, "is_train": is_train, "seed": seed}))
+        outs[f"{tag}_next_random"] = np.array(random.random())  # the global stream position after the call
+    nb = json.load(open("/root/reference/notebooks/ResDif_execution.ipynb"))
+    c11 = yaml.safe_load("".join(nb["cells"][11]["source"]).split("\n", 1)[1])  # drop the %%writefile line
+    logged = ref_utils.log_configs(TrainConfig.from_dict(c11))
+    np.savez_compressed(os.path.join(HERE, "prompt_embeds.npz"), fixed=fixed.numpy(), batch_json=np.array(json.dumps(
+        {"txt": [c if isinstance(c, str) else list(map(str, c)) for c in batch["txt"]], "ndarray_items": [2]})),
+        c11_config_json=np.array(json.dumps(c11)), log_configs_json=np.array(json.dumps(logged)),
+        log_configs_keys=np.array(json.dumps(list(logged))), **outs)
+    print("prompts ok", fixed.shape, {k: v.shape for k, v in outs.items() if k.endswith("_small")}, len(c11), "config keys")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "prompts":
+        gen_prompts()
+        sys.exit(0)
+    gen_prompts()
     gen_forward_shift()
     gen_condition_and_vis()
     gen_adapter()

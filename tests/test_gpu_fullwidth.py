@@ -108,6 +108,45 @@ def test_sd15_bench_batch_bf16_with_shipped_table(sd15, engines):
     assert float(per.max()) < BF16_TOL, per
 
 
+def test_sd15_consumes_the_reference_producers_fixed_embeds(sd15, engines, golden_dir):
+    """SURVEY.md 8 a10 at the real width: the `[1, 77, 768]` tensor the REFERENCE's `get_fixed_prompt_embeds` returned for the
+    stub tokenizer / encoder (tests/golden/prompt_embeds.npz, made by tests/golden/make_golden.py) as fp16 on the device,
+    sliced `[0:1]` as `log_validation` slices it (res_srdiff.py:67,75), B = 1."""
+    import numpy as np
+    from oracle import unet as ou
+    cfg, up, lora = sd15
+    fixed = torch.from_numpy(np.load(os.path.join(golden_dir, "prompt_embeds.npz"))["fixed"])
+    assert tuple(fixed.shape) == (1, 77, 768)
+    f16 = fixed.to(torch.float16).cuda()
+    g = torch.Generator().manual_seed(1119)
+    x = torch.randn((1, 4, 32, 32), generator=g)
+    ref = ou.unet_forward({**up, **lora}, cfg, x, torch.tensor(961), f16.float().cpu())
+    out = engines["f32"](x.cuda(), torch.tensor(961).cuda(), encoder_hidden_states=f16[0:1]).sample
+    assert rel(out, ref) < 1e-3 and maxrel(out, ref) < 1e-3
+    assert rel(engines["bf16"](x.cuda(), torch.tensor(961).cuda(), encoder_hidden_states=f16[0:1]).sample, ref) < BF16_TOL
+
+
+def test_sd15_bf16_forward_with_poisoned_lds_gives_the_same_bits(engines):
+    """The whole SD-1.5 forward at the bench batch (the shipped table's kernels, two workgroups per CU everywhere) with every
+    GEMM workgroup's LDS pre-filled with NaN bytes (`mrisr_debug_gemm_flags(2048)`, see test_gpu_ops.py): bit-identical to the
+    normal run - no kernel of the step reads LDS that its own DMA has not written."""
+    import ctypes as C
+    from mrisr import _lib as L
+    g = torch.Generator().manual_seed(1117)
+    x = torch.randn((32, 4, 32, 32), generator=g).cuda()
+    ctx = torch.randn((32, 77, 768), generator=g).cuda()
+    t = torch.tensor(333).cuda()
+    clean = engines["bf16"](x, t, encoder_hidden_states=ctx).sample.clone()
+    try:
+        L.lib().mrisr_debug_gemm_flags(C.c_int(2048))
+        for rep in range(2):
+            got = engines["bf16"](x, t, encoder_hidden_states=ctx).sample
+            assert bool(torch.isfinite(got.float()).all()), rep
+            assert torch.equal(got, clean), (rep, float((got.float() - clean.float()).abs().max()))
+    finally:
+        L.lib().mrisr_debug_gemm_flags(C.c_int(0))
+
+
 def test_sd15_ddim_three_steps_through_the_captured_graph(sd15, engines):
     """(iii) three DDIM steps through the hipGraph-captured sampler vs oracle.sampler.ddim_sample: f32 at B=2 (1e-3), bf16 at the
     bench batch B=32 (rows 0-1 against the same oracle trajectory)."""

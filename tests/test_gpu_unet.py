@@ -299,11 +299,14 @@ def test_reference_eager_loop_over_product_models_matches_reference_trajectory(t
         return unet(x, t, **kw)
 
     traj = osa.res_srdiff_sample(unet_spy, cnet, lr_lat, ctx[0:1], cond, sched.timesteps, sched.alphas_cumprod, init_noise, step_noise)
-    assert len(traj) == 6 and all(s == (0, "cuda", torch.int64, 12, (1, cfg.block_out_channels[-1], 1, 1)) for s in seen), seen
-    for k, x in enumerate(traj):
+    assert len(traj) == 6 and all(s == (0, "cuda", torch.int64, 12, (1, cfg.block_out_channels[-1], 8, 8)) for s in seen), seen  # 512^2 px -> 64^2 latents -> 8^2 mid
+    assert g["states"].shape[0] == 5  # the golden holds the state BEFORE each of the 5 steps; the final one is scored through the panel
+    for k, x in enumerate(traj[:5]):
         assert x.is_cuda and x.dtype == torch.float32
         r = rel(x, torch.from_numpy(g["states"][k]))
         assert r < 1e-3, (k, r)  # north_star: 1e-3 rel f32
+    gen = mrisr.decode_to_vis(traj[5], _StubVAE())  # res_srdiff.py:100 on the loop's result
+    assert np.abs(gen[::8, ::8, 0].astype(int) - g["gen_panel_small"].astype(int)).max() <= 1
 
 
 def test_sampler_trajectory_states_and_graph_equals_eager(tiny, golden_dir):

@@ -63,6 +63,11 @@ typedef struct {
     int32_t fp8_linears;            /* 0: off; 1: K = 320 projections; 2: K = 320 and 640 (bf16 models): these projections of the transformer blocks - incl. the LoRA
                                        targets to_q/k/v, to_out - run with OCP e4m3 operands on the fp8 MFMA (per-output-channel
                                        weight scales, per-row activation scales computed in-kernel), f32 accumulate; BASELINE configs[4] */
+    int32_t fp8_attention;          /* 1 (bf16 models, flash_attention): Q K^T and P V of every attention on the fp8 MFMA (OCP e4m3 operands,
+                                       per-head scales, f32 softmax and accumulate); the log-sum-exp kept for the backward is unchanged */
+    int32_t fp8_train;              /* 1: mrisr_train_step runs its FORWARD with the fp8 projections / fp8 attention selected above
+                                       and its backward in bf16 with f32 accumulation, straight through the quantisers ("mixed-precision
+                                       training" of BASELINE configs[4]); 0: the training forward stays bf16 whatever the inference mode is */
 } mrisr_unet_cfg;
 
 typedef struct mrisr_model mrisr_model; /* UNet2DConditionModel or ControlNetModel */

@@ -296,6 +296,340 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
 }
 
 // ================================================================================================
+// fp8 attention (BASELINE configs[4]: "fp8 (CDNA4 MFMA) attention"): Q K^T and P V on v_mfma_f32_16x16x32_fp8_fp8 (OCP e4m3
+// operands, f32 accumulate), softmax in f32 exactly as above.  Scales are PER HEAD and chosen so that no score ever needs a
+// multiply on the (VALU-bound) softmax path:
+//   * Q K^T: with c = sqrt(amax|Q| * scale*log2e / amax|K|) the operands K8 = e4m3(K * c) and Q8 = e4m3(Q * scale*log2e / c) have
+//     the same amax and their product is the score in log2 units directly - the matrix core's output (minus the running
+//     reference, which rides in as the C operand as before) goes straight into v_exp_f32;
+//   * P V: p = 2^(s - m) <= 2^8 fits e4m3 as it is; V8 = e4m3(V / sV), sV = amax|V| / 448, and sV is folded into the final
+//     1 / rowsum factor.  The row sum is still one more row of V^T (row hd = 1.0, exact in e4m3), so it is the sum of the
+//     QUANTISED p - numerator and denominator see the same rounding.
+// A pre-pass (one workgroup per (batch, head)) finds the three amax values and writes K8 / V8^T (half the bytes of the bf16
+// tiles); Q is quantised in the attention kernel's own prologue, where it is pre-scaled anyway.  The log-sum-exp output for the
+// (bf16) backward is unchanged.
+// ================================================================================================
+typedef long f8x8;  // 8 e4m3 values = one MFMA operand
+struct AttnQuantArgs {
+    const void* q; const void* k; const void* vt;
+    void* k8; void* vt8;
+    float* scales;  // [B*H][4]: Q multiplier (scale*log2e / c), c, sV, unused
+    int nqpad, nkpad, dpad;
+    float sl2;
+};
+__device__ __forceinline__ float amax8(const bf16x8& v, float m) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    return m;
+}
+__device__ __forceinline__ f8x8 quant8_clamped(const bf16x8& x, float mul) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf((float)x[e] * mul, -448.f), 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (f8x8)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__global__ __launch_bounds__(256) void attn_quant_fp8_kernel(const AttnQuantArgs a) {
+    __shared__ float red[3][4];
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    const bf16* q = reinterpret_cast<const bf16*>(a.q) + (size_t)bh * a.nqpad * a.dpad;
+    const bf16* k = reinterpret_cast<const bf16*>(a.k) + (size_t)bh * a.nkpad * a.dpad;
+    const bf16* vt = reinterpret_cast<const bf16*>(a.vt) + (size_t)bh * a.dpad * a.nkpad;
+    const int nq8 = a.nqpad * a.dpad / 8, nk8 = a.nkpad * a.dpad / 8;
+    float mq = 0.f, mk = 0.f, mv = 0.f;
+    for (int i = tid; i < nq8; i += 256) mq = amax8(*reinterpret_cast<const bf16x8*>(q + (size_t)i * 8), mq);
+    for (int i = tid; i < nk8; i += 256) {
+        mk = amax8(*reinterpret_cast<const bf16x8*>(k + (size_t)i * 8), mk);
+        mv = amax8(*reinterpret_cast<const bf16x8*>(vt + (size_t)i * 8), mv);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        mq = fmaxf(mq, __shfl_xor(mq, o));
+        mk = fmaxf(mk, __shfl_xor(mk, o));
+        mv = fmaxf(mv, __shfl_xor(mv, o));
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = mq; red[1][tid >> 6] = mk; red[2][tid >> 6] = mv; }
+    __syncthreads();
+    mq = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    mk = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    mv = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    const float c = (mq > 0.f && mk > 0.f) ? sqrtf(mq * a.sl2 / mk) : 1.0f;
+    const float sv = mv > 0.f ? mv * (1.0f / 448.0f) : 1.0f;
+    if (tid == 0) {
+        float* sc = a.scales + (size_t)bh * 4;
+        sc[0] = a.sl2 / c; sc[1] = c; sc[2] = sv; sc[3] = 0.f;
+    }
+    const float isv = 1.0f / sv;
+    char* k8 = reinterpret_cast<char*>(a.k8) + (size_t)bh * a.nkpad * a.dpad;
+    char* v8 = reinterpret_cast<char*>(a.vt8) + (size_t)bh * a.dpad * a.nkpad;
+    for (int i = tid; i < nk8; i += 256) {  // (re-read: the head's 2 x nkpad x dpad x 2 bytes were just streamed through this CU's L2)
+        *reinterpret_cast<f8x8*>(k8 + (size_t)i * 8) = quant8_clamped(*reinterpret_cast<const bf16x8*>(k + (size_t)i * 8), c);
+        *reinterpret_cast<f8x8*>(v8 + (size_t)i * 8) = quant8_clamped(*reinterpret_cast<const bf16x8*>(vt + (size_t)i * 8), isv);
+    }
+}
+
+template <int DPAD, int DB, int QF, bool ONES>
+__global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(const AttnArgs a) {
+    constexpr int KT = 64;
+    constexpr int KSTEPS = DPAD / 32;
+    constexpr int KP = DPAD + 16;           // K8 tile row pitch (bytes): 16-byte aligned rows, fragment reads (8 B) <= 2-way conflicts
+    constexpr int VP = KT + 16;             // V8^T tile row pitch (bytes): the 4-byte fragment reads of a wave hit 64 distinct banks
+    constexpr int NCH = KT * DPAD / 16;     // 16-byte chunks per tile (K and V^T alike)
+    constexpr int CPT = (NCH + 255) / 256;
+    constexpr float THR = 8.0f;
+    __shared__ __attribute__((aligned(16))) char k_lds2[2][KT * KP];
+    __shared__ __attribute__((aligned(16))) char v_lds2[2][DPAD * VP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    int bh = blockIdx.y, qblk = blockIdx.x;
+    if (a.xcd_map) {
+        const int L = blockIdx.x + blockIdx.y * gridDim.x;
+        const int slot = L >> 3;
+        bh = (slot / (int)gridDim.x) * 8 + (L & 7);
+        qblk = slot % (int)gridDim.x;
+    }
+    const int q0 = (qblk * 4 + wave) * (16 * QF);
+    const bf16* qb = reinterpret_cast<const bf16*>(a.q) + (size_t)bh * ((a.nq + 63) / 64 * 64) * DPAD;
+    const char* kb = reinterpret_cast<const char*>(a.k8) + (size_t)bh * a.nkpad * DPAD;
+    const char* vb = reinterpret_cast<const char*>(a.vt8) + (size_t)bh * DPAD * a.nkpad;
+    const float qmul = a.f8_scales[(size_t)bh * 4 + 0];
+    const float sv = a.f8_scales[(size_t)bh * 4 + 2];
+
+    f8x8 qf[QF][KSTEPS];
+    const int q_last = (a.nq + 63) / 64 * 64 - 1;
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk)
+            qf[f][kk] = quant8_clamped(*reinterpret_cast<const bf16x8*>(qb + (size_t)min(q0 + f * 16 + fr, q_last) * DPAD + kk * 32 + fg * 8), qmul);
+
+    f32x4 oacc[QF][DB];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_run[f] = 0.f;
+        l_run[f] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) oacc[f][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    uint4v kreg[CPT], vreg[CPT];
+    const char* kptr[CPT];
+    const char* vptr[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = min(i * 256 + tid, NCH - 1);
+        kptr[i] = kb + (size_t)(c / (DPAD / 16)) * DPAD + (c % (DPAD / 16)) * 16;  // K8 tile: KT rows x DPAD/16 chunks
+        vptr[i] = vb + (size_t)(c >> 2) * a.nkpad + (c & 3) * 16;                  // V8^T tile: DPAD rows x 4 chunks
+    }
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            kreg[i] = *reinterpret_cast<const uint4v*>(kptr[i]);
+            vreg[i] = *reinterpret_cast<const uint4v*>(vptr[i]);
+            kptr[i] += KT * DPAD;
+            vptr[i] += KT;
+        }
+    };
+    auto commit = [&](int buf) {
+        char* k_l = k_lds2[buf];
+        char* v_l = v_lds2[buf];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = i * 256 + tid;
+            if (NCH % 256 != 0 && c >= NCH) continue;
+            {
+                const int row = c / (DPAD / 16), ch = c % (DPAD / 16);
+                *reinterpret_cast<uint4v*>(k_l + row * KP + ch * 16) = kreg[i];
+            }
+            {
+                const int row = c >> 2, ch = c & 3;
+                uint4v v = vreg[i];
+                if (ONES && row == a.hd) v = uint4v{0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u};  // 1.0 in e4m3: the row-sum row
+                *reinterpret_cast<uint4v*>(v_l + row * VP + ch * 16) = v;
+            }
+        }
+    };
+
+    const int ntiles = (a.nk + KT - 1) / KT;
+    fetch();
+    commit(0);
+    if (ntiles > 1) fetch();
+    for (int t = 0; t < ntiles; ++t) {
+        const int kt0 = t * KT;
+        const char* k_lds = k_lds2[t & 1];
+        const char* v_lds = v_lds2[t & 1];
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch();
+        }
+        f32x4 s[QF][4];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f8x8 kf = *reinterpret_cast<const f8x8*>(k_lds + (tt * 16 + fr) * KP + kk * 32 + fg * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    const float nm = -m_run[f];
+                    const f32x4 c = kk == 0 ? f32x4{nm, nm, nm, nm} : s[f][tt];
+                    s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kf, qf[f][kk], c, 0, 0, 0);
+                }
+            }
+        }
+        const bool ragged = kt0 + KT > a.nk;
+        f8x8 pw[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            if (ragged) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt0 + tt * 16 + fg * 4 + r >= a.nk) s[f][tt][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
+#pragma unroll
+            for (int tt = 1; tt < 4; ++tt) {
+                mx = fmaxf(fmaxf(mx, s[f][tt][0]), s[f][tt][1]);
+                mx = fmaxf(fmaxf(mx, s[f][tt][2]), s[f][tt][3]);
+            }
+            if (t == 0 || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {
+                mx = xor_max(mx);
+                const float dlt = t == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-dlt);
+                m_run[f] += dlt;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[f][tt][r] -= dlt;
+                if (t != 0) {
+                    l_run[f] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
+                }
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                int w[2] = {0, 0};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int tt = sub * 2 + h2;
+                    const float p0 = __builtin_amdgcn_exp2f(s[f][tt][0]), p1 = __builtin_amdgcn_exp2f(s[f][tt][1]);
+                    const float p2 = __builtin_amdgcn_exp2f(s[f][tt][2]), p3 = __builtin_amdgcn_exp2f(s[f][tt][3]);
+                    w[h2] = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, w[h2], false);
+                    w[h2] = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, w[h2], true);
+                    if (!ONES) {  // the sum of the QUANTISED p (what the P V product sees)
+                        const float q0f = __builtin_amdgcn_cvt_f32_fp8(w[h2], 0), q1f = __builtin_amdgcn_cvt_f32_fp8(w[h2], 1);
+                        const float q2f = __builtin_amdgcn_cvt_f32_fp8(w[h2], 2), q3f = __builtin_amdgcn_cvt_f32_fp8(w[h2], 3);
+                        ps += (q0f + q1f) + (q2f + q3f);
+                    }
+                }
+                pw[f][sub] = (f8x8)(((unsigned long)(unsigned)w[1] << 32) | (unsigned)w[0]);
+            }
+            if (!ONES) l_run[f] += ps;
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const char* vrow = v_lds + (d * 16 + fr) * VP + sub * 32 + fg * 4;
+                const unsigned lo = *reinterpret_cast<const unsigned*>(vrow);
+                const unsigned hi = *reinterpret_cast<const unsigned*>(vrow + 16);
+                const f8x8 vf = (f8x8)(((unsigned long)hi << 32) | lo);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf, pw[f][sub], oacc[f][d], 0, 0, 0);
+            }
+        }
+    }
+
+    const int b = bh / a.H, h = bh - b * a.H;
+    bf16* ob = reinterpret_cast<bf16*>(a.out);
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float lsum;
+        if (ONES) {
+            float cand = 0.f;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (d * 16 + fg * 4 + r == a.hd) cand = oacc[f][d][r];
+            lsum = xor_sum(cand);
+        } else {
+            lsum = xor_sum(l_run[f]);
+        }
+        const float inv = sv / lsum;  // V8 = V / sV
+        const int q = q0 + f * 16 + fr;
+        if (a.lse && fg == 0 && q <= q_last)
+            a.lse[(size_t)bh * (q_last + 1) + q] = q < a.nq ? m_run[f] + __builtin_amdgcn_logf(lsum) : INFINITY;
+        if (q < a.nq) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int dd = d * 16 + fg * 4;
+                if (dd < a.hd) {
+                    bf16x4 o = {(bf16)(oacc[f][d][0] * inv), (bf16)(oacc[f][d][1] * inv), (bf16)(oacc[f][d][2] * inv),
+                                (bf16)(oacc[f][d][3] * inv)};
+                    *reinterpret_cast<bf16x4*>(ob + ((size_t)b * a.nq + q) * (a.H * a.hd) + h * a.hd + dd) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int DPAD, int DB>
+static int launch_dpad_fp8(const AttnArgs& a, hipStream_t st) {
+    const int BH = a.B * a.H;
+    static const int xcd_env = [] { const char* e = getenv("MRISR_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    const_cast<AttnArgs&>(a).xcd_map = (xcd_env && BH % 8 == 0) ? 1 : 0;
+    ProfScope ps("flash_attention_fp8", 4.0 * BH * (double)a.nq * a.nk * a.hd, 1.0 * BH * (2.0 * 2.0 * a.nq * a.hd + 2.0 * a.nk * a.hd), st);
+    const bool ones = a.hd < DB * 16;
+    if (a.nq >= 128) {
+        if (ones) hipLaunchKernelGGL((attn_fwd_fp8_kernel<DPAD, DB, 2, true>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_fp8_kernel<DPAD, DB, 2, false>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
+    } else {
+        if (ones) hipLaunchKernelGGL((attn_fwd_fp8_kernel<DPAD, DB, 1, true>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_fp8_kernel<DPAD, DB, 1, false>), dim3((a.nq + 63) / 64, BH), dim3(256), 0, st, a);
+    }
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// a.k8 / a.vt8: B*H*nkpad*dpad bytes each; a.f8_scales: B*H*4 floats (scratch of the caller)
+int launch_attention_fp8(const AttnArgs& a, hipStream_t st) {
+    MRISR_REQUIRE(a.nkpad % 64 == 0 && a.nk >= 1 && a.nk <= a.nkpad, "attention: key padding");
+    MRISR_REQUIRE(a.hd % 4 == 0 && a.hd <= a.dpad && a.dpad % 32 == 0, "attention: head dim");
+    MRISR_REQUIRE(a.k8 && a.vt8 && a.f8_scales, "fp8 attention: scratch for the quantised K / V^T and the per-head scales");
+    {
+        AttnQuantArgs qa;
+        qa.q = a.q; qa.k = a.k; qa.vt = a.vt; qa.k8 = a.k8; qa.vt8 = a.vt8; qa.scales = a.f8_scales;
+        qa.nqpad = (a.nq + 63) / 64 * 64; qa.nkpad = a.nkpad; qa.dpad = a.dpad;
+        qa.sl2 = a.scale * 1.4426950408889634f;
+        const int BH = a.B * a.H;
+        ProfScope ps("attention_quant_fp8", 0.0, (double)BH * a.dpad * (2.0 * qa.nqpad + 2.0 * 2.0 * a.nkpad + 2.0 * a.nkpad), st);
+        hipLaunchKernelGGL(attn_quant_fp8_kernel, dim3(BH), dim3(256), 0, st, qa);
+        MRISR_CHECK_HIP(hipGetLastError());
+    }
+    const int db = (a.hd + 15) / 16;
+#define ATT_CASE8(DP, DBV) if (a.dpad == DP && db == DBV) return launch_dpad_fp8<DP, DBV>(a, st);
+    ATT_CASE8(32, 1) ATT_CASE8(32, 2)
+    ATT_CASE8(64, 3) ATT_CASE8(64, 4)
+    ATT_CASE8(96, 5) ATT_CASE8(96, 6)
+    ATT_CASE8(128, 7) ATT_CASE8(128, 8)
+    ATT_CASE8(160, 9) ATT_CASE8(160, 10)
+#undef ATT_CASE8
+    MRISR_REQUIRE(false, "fp8 attention: unsupported (padded head dim, head dim) combination");
+    return 0;
+}
+
+// ================================================================================================
 // backward.  Two passes over the same tile loop, P recomputed from the log-sum-exp instead of stored:
 //   MODE 0 (dQ):     a wave OWNS 16*QF queries (Q, dO rows in registers) and streams key tiles
 //                    S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - D) * scale,  dQ^T += K^T dS^T

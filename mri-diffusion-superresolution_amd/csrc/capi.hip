@@ -965,7 +965,17 @@ static int op_attention_t(const mrisr_tensor* q, const mrisr_tensor* k, const mr
         AttnArgs a;
         a.q = qb.p; a.k = kb.p; a.vt = vb.p; a.out = out->data;
         a.B = B; a.H = H; a.nq = N; a.nk = Nk; a.nkpad = nkpad; a.hd = hd; a.dpad = dpad; a.scale = scale;
-        TRY(launch_attention_bf16(a, st));
+        if (flash == 2) {  // fp8 (OCP e4m3) Q K^T and P V
+            DevBuf k8, v8, sc;
+            TRY(k8.reserve((size_t)B * H * nkpad * dpad, false));
+            TRY(v8.reserve((size_t)B * H * nkpad * dpad, false));
+            TRY(sc.reserve((size_t)B * H * 4 * sizeof(float), false));
+            a.k8 = k8.p; a.vt8 = v8.p; a.f8_scales = static_cast<float*>(sc.p);
+            TRY(launch_attention_fp8(a, st));
+            MRISR_CHECK_HIP(hipStreamSynchronize(st));
+        } else {
+            TRY(launch_attention_bf16(a, st));
+        }
     } else {
         const int BH = B * H;
         TRY(sb.reserve((size_t)BH * N * nkpad * sizeof(float), false));

@@ -265,8 +265,13 @@ struct AttnArgs {
     float scale = 1.0f;
     float* lse = nullptr;  // optional [B*H][npad]: log2-domain log-sum-exp of scale*s (training keeps it for the backward)
     int xcd_map = 0;       // set by the launcher: all query blocks of a head on one XCD (needs B*H % 8 == 0)
+    // fp8 attention (launch_attention_fp8): caller's scratch for the e4m3 K / V^T (B*H*nkpad*dpad bytes each) and the per-head scales (B*H*4 floats)
+    void* k8 = nullptr;
+    void* vt8 = nullptr;
+    float* f8_scales = nullptr;
 };
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);
+int launch_attention_fp8(const AttnArgs& a, hipStream_t st);  // same operands (bf16, head-major) + the scratch fields; Q K^T and P V in OCP e4m3
 // flash attention backward (attn.hip): P is recomputed from Q, K and the forward's log-sum-exp, never materialised.
 //   head-major operands, pads zero:  q, doh [B*H][npad][dpad];  k, v [B*H][nkpad][dpad];  their transposes qt, doht
 //   [B*H][dpad][npad], kt [B*H][dpad][nkpad];  lse, dsum [B*H][npad] (dsum = rowsum(dO o O), 0 on pads).

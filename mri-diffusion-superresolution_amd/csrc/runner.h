@@ -116,8 +116,8 @@ struct Runner {
         if (g.out_mode != OUT_HEADS) { g.out = out; g.ldo = ldo; }
         // the row-panel kernel fuses LoRA only in the in-kernel rank-4 form
         if (lw.R && !(lw.r == 4 && lw.R <= 16 && lora_in_kernel())) g.no_rp = 1;
-        // fp8 operands (cfg.fp8_linears; inference only): when the row-panel fp8 kernel takes this launch
-        if (lw.w8 && sizeof(T) == 2 && !m.keep && !g.no_rp) {
+        // fp8 operands (cfg.fp8_linears; the training forward only with cfg.fp8_train): when the row-panel fp8 kernel takes this launch
+        if (lw.w8 && sizeof(T) == 2 && (!m.keep || m.cfg.fp8_train) && !g.no_rp) {
             GemmArgs probe = g;
             probe.w8 = lw.w8; probe.w_scale = lw.w_scale;
             if (lw.R) { probe.lora_a = lw.loraA; probe.lora_b = lw.loraB; probe.lora_r = lw.r; probe.lora_R = lw.R; probe.lora_a8 = lw.loraA8; probe.lora_a_scale = lw.loraA_scale; }
@@ -216,6 +216,16 @@ struct Runner {
             a.q = hb.q; a.k = k; a.vt = vt; a.out = out_rows;
             a.B = hb.B; a.H = hb.H; a.nq = hb.N; a.nk = nk; a.nkpad = nkpad; a.hd = hb.hd; a.dpad = hb.dpad;
             a.scale = scale;
+            if (m.cfg.fp8_attention) {  // BASELINE configs[4]: e4m3 Q K^T and P V; scratch for the quantised K / V^T + per-head scales
+                const size_t mk8 = m.arena.mark();
+                a.k8 = alloc((size_t)BH * nkpad * hb.dpad);
+                a.vt8 = alloc((size_t)BH * nkpad * hb.dpad);
+                a.f8_scales = static_cast<float*>(alloc((size_t)BH * 4 * sizeof(float)));
+                if (!a.k8 || !a.vt8 || !a.f8_scales) return 7;
+                const int rc = dry ? 0 : launch_attention_fp8(a, st);
+                if (!m.keep) m.arena.release(mk8);
+                return rc;
+            }
             if (dry) return 0;
             return launch_attention_bf16(a, st);
         }

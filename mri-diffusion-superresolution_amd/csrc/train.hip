@@ -335,6 +335,14 @@ struct Trainer : Runner<T> {
             fa.q = a->q; fa.k = a->k; fa.vt = a->vt; fa.out = out_rows;
             fa.B = hb.B; fa.H = hb.H; fa.nq = hb.N; fa.nk = a->nk; fa.nkpad = a->nkpad; fa.hd = hb.hd; fa.dpad = hb.dpad;
             fa.scale = scale; fa.lse = lse;
+            if (m.cfg.fp8_attention && m.cfg.fp8_train) {  // fp8 forward, bf16 backward from the same log-sum-exp (straight through)
+                fa.k8 = alloc((size_t)BH * a->nkpad * hb.dpad);
+                fa.vt8 = alloc((size_t)BH * a->nkpad * hb.dpad);
+                fa.f8_scales = static_cast<float*>(alloc((size_t)BH * 4 * sizeof(float)));
+                if (!fa.k8 || !fa.vt8 || !fa.f8_scales) return 7;
+                if (dry) return 0;
+                return launch_attention_fp8(fa, st);
+            }
             if (dry) return 0;
             return launch_attention_bf16(fa, st);
         }

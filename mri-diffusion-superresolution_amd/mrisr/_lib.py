@@ -30,7 +30,8 @@ class UNetCfg(C.Structure):
                 ("layers_per_block", C.c_int32), ("num_heads", C.c_int32), ("cross_attention_dim", C.c_int32),
                 ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float), ("cond_channels", C.c_int32),
                 ("cond_embed_channels", C.c_int32 * 4), ("compute_dtype", C.c_int32), ("lora_rank", C.c_int32),
-                ("lora_fused", C.c_int32), ("flash_attention", C.c_int32), ("fp8_linears", C.c_int32)]
+                ("lora_fused", C.c_int32), ("flash_attention", C.c_int32), ("fp8_linears", C.c_int32),
+                ("fp8_attention", C.c_int32), ("fp8_train", C.c_int32)]
 
 
 class AdapterCfg(C.Structure):

@@ -65,7 +65,7 @@ class _ControlNetOutput:
         self.mid_block_res_sample = mid
 
 
-def _c_cfg(cfg: UNetConfig, compute_dtype, lora_rank, lora_fused, flash, fp8=False) -> L.UNetCfg:
+def _c_cfg(cfg: UNetConfig, compute_dtype, lora_rank, lora_fused, flash, fp8=False, fp8_attention=False, fp8_train=False) -> L.UNetCfg:
     c = L.UNetCfg()
     c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
     c.num_levels = len(cfg.block_out_channels)
@@ -85,6 +85,8 @@ def _c_cfg(cfg: UNetConfig, compute_dtype, lora_rank, lora_fused, flash, fp8=Fal
     c.lora_fused = 1 if lora_fused else 0
     c.flash_attention = 1 if flash else 0
     c.fp8_linears = 2 if fp8 == "all" else (1 if fp8 else 0)  # True: the K = 320 projections; "all": K = 320 and 640
+    c.fp8_attention = 1 if fp8_attention else 0
+    c.fp8_train = 1 if fp8_train else 0
     return c
 
 
@@ -93,7 +95,11 @@ class _DeviceModel:
     _create = None
 
     def __init__(self, config=None, compute_dtype="bf16", lora_rank: int = 0, lora_alpha: Optional[float] = None,
-                 lora_fused: bool = True, flash_attention: bool = True, device="cuda", fp8=False):
+                 lora_fused: bool = True, flash_attention: bool = True, device="cuda", fp8=False, fp8_attention: bool = False,
+                 fp8_train: bool = False):
+        """``fp8`` / ``fp8_attention`` / ``fp8_train``: BASELINE configs[4] - OCP e4m3 operands on the fp8 MFMA for the K = 320 (``"all"``:
+        and 640) projections incl. the LoRA targets, for Q K^T / P V of every attention, and for the FORWARD of the training step
+        (backward in bf16, straight through).  Modes of the bf16 engine; off by default."""
         if not torch.cuda.is_available():
             raise L.MrisrError("mrisr needs an AMD GPU (gfx950); there is no CPU fallback")
         cfg = config if isinstance(config, UNetConfig) else (UNetConfig() if config is None else UNetConfig.from_oracle_like(config))
@@ -104,10 +110,14 @@ class _DeviceModel:
         self.lora_scale = (lora_alpha / lora_rank) if (lora_rank and lora_alpha is not None) else 1.0
         self._params: Dict[str, torch.Tensor] = {}
         self._h = C.c_void_p()
-        if fp8 and L.dtype_id(compute_dtype) != L.MRISR_BF16:
-            raise ValueError("fp8 projections are a mode of the bf16 engine")
-        self.fp8 = bool(fp8)
-        self._ccfg = _c_cfg(cfg, compute_dtype, lora_rank, lora_fused, flash_attention, fp8)
+        if (fp8 or fp8_attention or fp8_train) and L.dtype_id(compute_dtype) != L.MRISR_BF16:
+            raise ValueError("fp8 projections / attention are modes of the bf16 engine")
+        if fp8_attention and not flash_attention:
+            raise ValueError("fp8 attention is a mode of the flash kernel")
+        if fp8_train and not (fp8 or fp8_attention):
+            raise ValueError("fp8_train selects the fp8 forward for training: enable fp8 and / or fp8_attention too")
+        self.fp8, self.fp8_attention, self.fp8_train = bool(fp8), bool(fp8_attention), bool(fp8_train)
+        self._ccfg = _c_cfg(cfg, compute_dtype, lora_rank, lora_fused, flash_attention, fp8, fp8_attention, fp8_train)
         L.check(getattr(L.lib(), self._create)(C.byref(self._ccfg), C.byref(self._h)))
         self._finalized = False
         self.training = False

@@ -129,12 +129,13 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(q, k, v, heads, flash=True):
-    """q [B,N,C], k/v [B,Nk,C] -> [B,N,C]  (softmax(q k^T / sqrt(d)) v per head)."""
+def attention(q, k, v, heads, flash=True, fp8=False):
+    """q [B,N,C], k/v [B,Nk,C] -> [B,N,C]  (softmax(q k^T / sqrt(d)) v per head).  ``fp8``: Q K^T and P V with OCP e4m3 operands
+    (per-head scales, f32 softmax) - BASELINE configs[4]."""
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     out = torch.empty_like(q)
     tq, tk, tv, to = (L.as_tensor(t) for t in (q, k, v, out))
-    L.check(L.lib().mrisr_op_attention(C.byref(tq), C.byref(tk), C.byref(tv), heads, 1 if flash else 0, C.byref(to),
+    L.check(L.lib().mrisr_op_attention(C.byref(tq), C.byref(tk), C.byref(tv), heads, 2 if fp8 else (1 if flash else 0), C.byref(to),
                                        L.stream_ptr()))
     return out
 

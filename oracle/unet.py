@@ -320,14 +320,46 @@ def resnet_block(p: Params, name: str, x: Tensor, emb: Tensor, cfg: UNetConfig) 
     return x + h
 
 
+# BASELINE configs[4] (fp8 attention): when True, softmax(q k^T / sqrt(d)) v runs with fake-quantised OCP e4m3 operands and the
+# per-head scale rule of the product (csrc/attn.hip, "fp8 attention").  "parity unpinned", like FP8_LINEARS.
+FP8_ATTENTION = False
+
+
+def _e4m3(t: Tensor) -> Tensor:
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
+
+
+def sdpa_fp8_fake_quant(q: Tensor, k: Tensor, v: Tensor, bf16_inputs: bool = True) -> Tensor:
+    """[B, H, N, d] operands.  Per (batch, head): c = sqrt(amax|q| * sl2 / amax|k|), K8 = e4m3(k c), Q8 = e4m3(q sl2 / c) with
+    sl2 = log2(e) / sqrt(d) - their product is the score in log2 units; p = 2^(s - rowmax) is quantised as it is (the product keeps
+    p within (0, 2^8], a floating-point format does not care); V8 = e4m3(v / sV), sV = amax|v| / 448; the row sum is the sum of
+    the QUANTISED p.  ``bf16_inputs``: q / k / v reach the attention rounded to bf16 (the product's head-major buffers)."""
+    d = q.shape[-1]
+    if bf16_inputs:
+        q, k, v = (t.to(torch.bfloat16).to(t.dtype) for t in (q, k, v))
+    sl2 = 1.4426950408889634 * d ** -0.5
+    aq = q.abs().amax(dim=(-1, -2), keepdim=True)
+    ak = k.abs().amax(dim=(-1, -2), keepdim=True)
+    av = v.abs().amax(dim=(-1, -2), keepdim=True)
+    c = torch.where((aq > 0) & (ak > 0), (aq * sl2 / ak.clamp_min(1e-30)).sqrt(), torch.ones_like(aq))
+    sv = torch.where(av > 0, av / 448.0, torch.ones_like(av))
+    q8, k8, v8 = _e4m3(q * (sl2 / c)), _e4m3(k * c), _e4m3(v / sv)
+    s = torch.matmul(q8, k8.transpose(-1, -2))
+    p8 = _e4m3(torch.exp2(s - s.amax(dim=-1, keepdim=True)))
+    return sv * torch.matmul(p8, v8) / p8.sum(dim=-1, keepdim=True)
+
+
 def attention(p: Params, name: str, x: Tensor, ctx: Tensor, heads: int, lora_scale: float) -> Tensor:
     B, N, C = x.shape
     d = C // heads
     q = linear(p, name + ".to_q", x, lora_scale).view(B, N, heads, d).transpose(1, 2)
     k = linear(p, name + ".to_k", ctx, lora_scale).view(B, -1, heads, d).transpose(1, 2)
     v = linear(p, name + ".to_v", ctx, lora_scale).view(B, -1, heads, d).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    if FP8_ATTENTION:
+        o = sdpa_fp8_fake_quant(q, k, v)
+    else:
+        s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.matmul(torch.softmax(s, dim=-1), v)
     o = o.transpose(1, 2).reshape(B, N, C)
     return linear(p, name + ".to_out.0", o, lora_scale)
 

@@ -612,3 +612,149 @@ def test_gemm_kernels_with_poisoned_lds_give_the_same_bits():
                 assert torch.equal(got, clean), (name, rep)
     finally:
         lib.mrisr_debug_gemm_flags(C.c_int(0))
+
+
+@pytest.mark.parametrize("B,N,Nk,C,H", [(2, 256, 256, 320, 8), (1, 1024, 1024, 320, 8), (2, 64, 64, 1280, 8), (2, 16, 16, 1280, 8),
+                                        (2, 256, 77, 640, 8), (1, 200, 77, 64, 8), (1, 64, 64, 256, 8), (1, 100, 130, 1024, 8)])
+def test_attention_fp8(B, N, Nk, C, H):
+    """BASELINE configs[4] "fp8 attention": Q K^T and P V on v_mfma_f32_16x16x32_fp8_fp8 (OCP e4m3), f32 softmax, per-head scales
+    chosen so that the matrix core's output IS the log2-domain score (csrc/attn.hip).  Against the same quantisation rule done in
+    torch (oracle.unet.sdpa_fp8_fake_quant) the kernel is as close as the bf16 kernel is to exact SDPA - that pins operand layouts,
+    scales, the row-sum row and the normalisation; against exact SDPA the distance is the e4m3 noise (3 mantissa bits).  Every
+    padded head dim of the SD-1.5 levels, ragged query / key counts, the 77-key cross-attention shape."""
+    from mrisr import ops
+    from oracle import unet as ou
+    q, k, v = _rnd((B, N, C), "bf16", 121), _rnd((B, Nk, C), "bf16", 122), _rnd((B, Nk, C), "bf16", 123)
+    hm = lambda t: t.float().view(t.shape[0], t.shape[1], H, C // H).transpose(1, 2)
+    ref8 = ou.sdpa_fp8_fake_quant(hm(q), hm(k), hm(v)).transpose(1, 2).reshape(B, N, C)
+    exact = _sdpa(q, k, v, H)
+    y = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, fp8=True)
+    assert bool(torch.isfinite(y.float()).all())
+    e8, ex = rel(y, ref8), rel(y, exact)
+    # the kernel rounds p = 2^(s - m) against its lazily moved reference m, the torch rule against the true row maximum: the two p
+    # differ by a factor that is not a power of two, so their e4m3 roundings are independent - the distance between the two fp8
+    # results is the P quantisation noise (~3 %), not a layout check; the layout / scale checks proper are the structured cases below
+    assert e8 < 5e-2, (e8, ex)
+    assert 5e-3 < ex < 1.2e-1, ex   # fp8 really ran, and its error is the expected size
+    assert torch.equal(y, ops.attention(q.cuda(), k.cuda(), v.cuda(), H, fp8=True))
+    # (1) uniform attention (q = 0: every p is exactly 1): the output is the mean of the QUANTISED V - pins the V^T fragment layout,
+    #     sV, the row-sum row and the normalisation to bf16 rounding
+    z = torch.zeros_like(q)
+    y0 = ops.attention(z.cuda(), k.cuda(), v.cuda(), H, fp8=True)
+    r0 = ou.sdpa_fp8_fake_quant(hm(z), hm(k), hm(v)).transpose(1, 2).reshape(B, N, C)
+    assert rel(y0, r0) < 1e-2, rel(y0, r0)
+    # (2) one-hot attention (query i strongly aligned with key perm[i]: p is 1 for that key and underflows for the rest): the output
+    #     is row perm[i] of the quantised V - pins the Q / K fragment layouts, the score scale and the key order
+    perm = torch.randperm(Nk, generator=torch.Generator().manual_seed(5))[torch.arange(N) % Nk]
+    kk = torch.sign(_rnd((B, Nk, C), "f32", 127)).to(torch.bfloat16)  # +-1 keys: distinct directions, |k|^2 = d
+    qq = (kk[:, perm].float() * 6.0).to(torch.bfloat16)               # score of the aligned key: 6 sqrt(d) >> the others
+    y1 = ops.attention(qq.cuda(), kk.cuda(), v.cuda(), H, fp8=True)
+    r1 = ou.sdpa_fp8_fake_quant(hm(qq), hm(kk), hm(v)).transpose(1, 2).reshape(B, N, C)
+    assert rel(y1, r1) < 1e-2, rel(y1, r1)
+
+
+def test_attention_fp8_online_softmax_rescale_branch():
+    """The lazily moved reference of the fp8 kernel (guide rule 26): one key aligned with every query sits in the LAST tile."""
+    from mrisr import ops
+    from oracle import unet as ou
+    B, N, C, H = 1, 256, 320, 8
+    q, k, v = _rnd((B, N, C), "bf16", 124), _rnd((B, N, C), "bf16", 125), _rnd((B, N, C), "bf16", 126)
+    k[:, 250] = q.float().mean(1).to(torch.bfloat16) * 6.0
+    hm = lambda t: t.float().view(B, N, H, C // H).transpose(1, 2)
+    ref8 = ou.sdpa_fp8_fake_quant(hm(q), hm(k), hm(v)).transpose(1, 2).reshape(B, N, C)
+    y = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, fp8=True)
+    assert rel(y, ref8) < 5e-2, rel(y, ref8)
+    assert rel(y, _sdpa(q, k, v, H)) < 1.2e-1
+    # zero operands (amax = 0 in the scale rule) stay finite: uniform attention over V
+    z = torch.zeros((1, 64, 320), dtype=torch.bfloat16)
+    y0 = ops.attention(z.cuda(), z.cuda(), v[:, :64].cuda(), H, fp8=True)
+    assert rel(y0, v[:, :64].float().mean(1, keepdim=True).expand(-1, 64, -1)) < 5e-2
+
+
+def test_unet_fp8_attention_and_fp8_training_forward():
+    """configs[4] composed: fp8 projections + fp8 attention in the model - inference against the fake-quant oracle; and the
+    mixed-precision TRAINING step (`fp8_train`): forward through the fp8 kernels, backward in bf16 straight through the quantisers.
+    Checked: the fp8 kernels really ran (profiler classes) in both; the fp8 loss is the fake-quant oracle's loss; the LoRA gradient
+    bucket stays within the fp8 noise of exact autograd; with fp8_train off the training forward is the bf16 one bit for bit."""
+    import ctypes as C
+    import json
+
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg = ou.UNetConfig(block_out_channels=(320, 640), attn_levels=(True, True), cross_attention_dim=64)
+    up = ou.init_unet_params(cfg, seed=271, perturb_norm=True)
+    lora = ou.init_lora_params(up, rank=4, seed=272)
+    p = {**up, **lora}
+    g = torch.Generator().manual_seed(273)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, 64), generator=g)
+    tgt = torch.randn((2, 4, 16, 16), generator=g)
+    t = torch.tensor([40, 700])
+    served = ("proj_in", "proj_out", "to_q", "to_k", "to_v", "to_out.0", "ff.net.0.proj")
+    lp = {k_: v_.clone().requires_grad_(True) for k_, v_ in lora.items()}
+    with torch.enable_grad():
+        pred = ou.unet_forward({**up, **lp}, cfg, x, t, ctx)
+        loss_exact = torch.nn.functional.mse_loss(pred, tgt)
+        loss_exact.backward()
+    try:
+        ou.FP8_ATTENTION = True
+        ref8a = ou.unet_forward(p, cfg, x, t, ctx)          # fp8 attention only
+        # the training forward keeps LayerNorm / GEGLU as their own kernels, so ALL served K = 320 / 640 linears run in fp8 there
+        ou.FP8_LINEARS = lambda name, K: K in (320, 640) and name.endswith(served)
+        ref8_train = ou.unet_forward(p, cfg, x, t, ctx)
+    finally:
+        ou.FP8_LINEARS = None
+        ou.FP8_ATTENTION = False
+    lib = L.lib()
+
+    def classes_of(fn):
+        lib.mrisr_prof_reset(); lib.mrisr_prof_enable(1)
+        out = fn()
+        torch.cuda.synchronize(); lib.mrisr_prof_enable(0)
+        buf = C.create_string_buffer(1 << 20)
+        n = lib.mrisr_prof_report(buf, len(buf))
+        lib.mrisr_prof_reset()
+        return out, json.loads(buf.value[:n].decode())
+
+    xa, ta, ca, ga = x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda()
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, fp8_attention=True)
+    net.load_state_dict(p)
+    net(xa, ta, encoder_hidden_states=ca)
+    out, cls = classes_of(lambda: net(xa, ta, encoder_hidden_states=ca).sample)
+    assert "flash_attention_fp8" in cls and "attention_quant_fp8" in cls and "flash_attention" not in cls, sorted(cls)
+    e = rel(out, ref8a)
+    print(f"fp8-attention engine vs fake-quant oracle {e:.4e}; vs exact oracle {rel(out, pred.detach()):.4e}")
+    assert e < 5e-2 and rel(out, pred.detach()) < 8e-2
+    # ---- mixed-precision training ----
+    net8 = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, lora_fused=True, fp8="all", fp8_attention=True,
+                                      fp8_train=True)
+    net8.load_state_dict(p)
+    tr8 = mrisr.LoRATrainer(net8)
+    tr8.forward_backward(xa, ta, ca, ga)  # plan + tune
+    tr8.zero_grad()
+    (loss8, pred8), cls = classes_of(lambda: tr8.forward_backward(xa, ta, ca, ga, return_pred=True))
+    assert "flash_attention_fp8" in cls and any(k_.startswith("gemm_fp8_rp") for k_ in cls), sorted(cls)
+    assert any(k_.startswith("flash_attention_bwd") for k_ in cls), sorted(cls)   # bf16 flash backward from the fp8 forward's log-sum-exp
+    loss8_ref = float(torch.nn.functional.mse_loss(ref8_train, tgt))
+    flat_ref = torch.cat([lp[k_].grad.reshape(-1) for k_, _, _ in tr8.layout])
+    e_pred, e_grad = rel(pred8, ref8_train), rel(tr8.grad, flat_ref)
+    print(f"fp8 training forward vs fake-quant oracle {e_pred:.4e}; loss {float(loss8):.5f} vs {loss8_ref:.5f} (exact {float(loss_exact):.5f}); "
+          f"LoRA gradient bucket vs exact autograd {e_grad:.4e}")
+    assert e_pred < 8e-2 and abs(float(loss8) - loss8_ref) / loss8_ref < 3e-2
+    assert e_grad < 2.5e-1, e_grad
+    # fp8_train off: the same model flags train through the bf16 forward, bit for bit the plain bf16 model's step
+    netb = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, lora_fused=True, fp8="all", fp8_attention=True)
+    netb.load_state_dict(p)
+    net16 = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, lora_fused=True)
+    net16.load_state_dict(p)
+    trb, tr16 = mrisr.LoRATrainer(netb), mrisr.LoRATrainer(net16)
+    lb, pb = trb.forward_backward(xa, ta, ca, ga, return_pred=True)
+    l16, p16 = tr16.forward_backward(xa, ta, ca, ga, return_pred=True)
+    print(f"fp8_train off vs plain bf16: pred equal {torch.equal(pb, p16)}, grad rel {rel(trb.grad, tr16.grad):.3e}")
+    assert torch.equal(pb, p16) and rel(trb.grad, tr16.grad) < 1e-6
+    assert rel(tr16.grad, flat_ref) < 6e-2
+    with pytest.raises(ValueError):
+        mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", fp8_train=True)
+    with pytest.raises(ValueError):
+        mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", fp8_attention=True)

@@ -910,7 +910,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * 2) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // tile kt visible to every wave; every wave has finished tile kt - 1 (its slot is refilled below)
+            // RAW barrier, never __syncthreads() here: an LDS-DMA in flight is a pending LDS write on the VM counter, so the fence
+            // inside __syncthreads() makes hipcc emit `s_waitcnt vmcnt(0)` in front of the s_barrier - it drained the whole ring on
+            // every K step (rounds 1-2 measured "3 or 4 stages = 2 stages" with exactly that: the counted wait two lines up was
+            // followed by a vmcnt(0) in the ISA).  Tile kt is ordered for every wave's ds_read by each issuing wave's counted
+            // vmcnt + this barrier; the slot refilled below was last READ in compute(kt - 1), whose ds_reads have all returned
+            // (their MFMAs consumed them; lgkmcnt(0) makes it explicit) before any wave passes this barrier.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (kt + NSTAGE - 1 < kt_end) stage(kt + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
             compute(slot);
             slot = slot + 1 == NSTAGE ? 0 : slot + 1;
@@ -1421,10 +1428,13 @@ __global__ __launch_bounds__(512, 2) void gemm_halo8_kernel(const GemmArgs g) {
             if (p + D < P) stage_w(p + D);  // into the slot phase p - 1 read: free since the barrier that ended it
             compute(p);
             const int tap = p - (p / 9) * 9;
+            // RAW barriers in this loop (see gemm_bl_kernel's ring): __syncthreads() would put a vmcnt(0) in front of every s_barrier
+            // and drain the weight ring each phase - which is what rounds 1-2 measured as "ring depth makes no difference"
             if (tap == 8 && p + 1 < P) {
-                __syncthreads();  // every wave is done with this chunk's patch
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's patch
                 stage_patch(ch_beg + (p + 1) / 9);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch pieces are the youngest: everything has landed
             } else {
                 // phase p + 1's weights must have landed; the stages issued after them (phases p + 2 .. p + D) may stay in flight
                 const int young = min(D - 1, P - 2 - p);
@@ -1432,8 +1442,10 @@ __global__ __launch_bounds__(512, 2) void gemm_halo8_kernel(const GemmArgs g) {
                 else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_IT) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
+        __syncthreads();  // (drained) the epilogue reuses the stage buffers
     }
 
     if (g.splitk > 1) {
@@ -2585,7 +2597,10 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     X(33, 64, 64, 2, 2, 3)     \
     X(34, 64, 128, 2, 2, 3)    \
     X(35, 128, 64, 2, 2, 3)    \
-    X(36, 128, 128, 2, 2, 3)
+    X(36, 128, 128, 2, 2, 3)   \
+    X(37, 128, 160, 2, 2, 4)   \
+    X(38, 128, 128, 2, 2, 4)   \
+    X(39, 64, 160, 2, 2, 3)
 
 static int prepare_bls() {
 #define X(id, bm, bn, wm, wn, ns) if (prepare_bl<bm, bn, wm, wn, ns>()) return 1;
@@ -3041,7 +3056,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
             static const std::string skip = [] { const char* e = getenv("MRISR_TUNE_SKIP"); return std::string(e ? e : ""); }();
             if (!skip.empty() && ("," + skip + ",").find("," + std::to_string(tile) + ",") != std::string::npos) continue;
         }
-        if (tile >= 32 && tile <= 36 && !ring_ok(g, tile)) continue;  // counted-ring variants: exact plain GEMMs only
+        if (tile >= 32 && tile <= 39 && !ring_ok(g, tile)) continue;  // counted-ring variants: exact plain GEMMs only
         if (is_halo8(tile)) { if (!halo8_ok(g)) continue; }
         else if (tile >= 40 && tile < 50 && !halo_ok(g, halo_bm(tile))) continue;  // LDS-halo conv kernels: stride-1 3x3, whole tiles per image
         if (tile >= 50 && tile < 60 && !ws_ok(g, tile)) continue;  // weight-stationary kernels: short-K plain GEMMs that tile exactly
@@ -3050,7 +3065,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
         if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
         for (int s = 1; s <= 32; s *= 2) {
-            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50 || (tile >= 32 && tile <= 36))) break;
+            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50 || (tile >= 32 && tile <= 39))) break;
             const size_t pbytes = s > 1 ? (size_t)s * g.M * g.N * 4 * zb : 0;
             if (pbytes > ((size_t)1 << 30)) break;
             if (s > 1 && g_ts.reserve(4, pbytes, false)) return 1;
@@ -3129,7 +3144,7 @@ int gemm_choose(GemmArgs& g, bool is_bf16) {
         plan(g, is_bf16, 0, &t, &s);
     }
     (void)cs;
-    if ((t >= 60 && !rp_ok(g, t)) || (t >= 32 && t <= 36 && (!ring_ok(g, t) || s > 1)) || (is_halo8(t) && !halo8_ok(g))) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
+    if ((t >= 60 && !rp_ok(g, t)) || (t >= 32 && t <= 39 && (!ring_ok(g, t) || s > 1)) || (is_halo8(t) && !halo8_ok(g))) plan(g, is_bf16, 0, &t, &s);  // (a table entry tuned without this launch's operand forms)
     if (g_force_split > 1 && g.act != ACT_GEGLU && g.K / (is_bf16 ? 64 : 32) >= g_force_split && !g.lora_a) {
         s = g_force_split;
         if (t >= 50) t = is_bf16 ? 14 : 1;

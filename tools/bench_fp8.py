@@ -34,7 +34,8 @@ x_T = (lr_lat + (1 - a_T) ** 0.5 * noise).contiguous()
 lib = L.lib()
 out = {"config": f"configs[4] inference leg: 256^2, SD-1.5 UNet + rank-4 LoRA, {nsteps}-step DDIM, bs={B}, 1 GPU", "engines": {}}
 finals = {}
-for name, kw in (("bf16", {}), ("fp8", {"fp8": True})):
+# "fp8": the K = 320 projections (round 2); "fp8_attn": those + every attention's Q K^T / P V in e4m3 (round 3: the whole of configs[4]'s inference side)
+for name, kw in (("bf16", {}), ("fp8", {"fp8": True}), ("fp8_attn", {"fp8": True, "fp8_attention": True})):
     unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4, **kw)
     unet.load_state_dict(sd)
     smp = mrisr.Sampler(unet, sched, kind="ddim")
@@ -60,9 +61,15 @@ for name, kw in (("bf16", {}), ("fp8", {"fp8": True})):
     lib.mrisr_prof_reset()
     rp = {k: v for k, v in cls.items() if "_rp" in k}
     fl, ms = sum(v["flops"] for v in rp.values()), sum(v["ms"] for v in rp.values())
+    att = {k: v for k, v in cls.items() if k.startswith(("flash_attention", "attention_quant"))}
+    afl, ams = sum(v["flops"] for v in att.values()), sum(v["ms"] for v in att.values())
     e = {"slices_per_s": B / dt, "ms_per_denoising_step": dt * 1e3 / nsteps, "finite": bool(torch.isfinite(lat).all()),
-         "row_panel_kernels": {"classes": sorted(rp), "ms_per_step": ms / 2, "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms else 0.0}}
-    if name == "fp8":
+         "row_panel_kernels": {"classes": sorted(rp), "ms_per_step": ms / 2, "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms else 0.0},
+         "attention_kernels": {"classes": {k: round(v["ms"] / 2, 4) for k, v in att.items()}, "ms_per_step": ams / 2,
+                               "achieved_tflops": afl / (ams * 1e-3) / 1e12 if ams else 0.0}}
+    if name == "fp8_attn":
+        e["attention_kernels"]["frac_of_fp8_peak_5pf"] = e["attention_kernels"]["achieved_tflops"] / 5000.0
+    if name.startswith("fp8"):
         t = e["row_panel_kernels"]["achieved_tflops"]
         e["row_panel_kernels"]["frac_of_fp8_peak_5pf"] = t / 5000.0
         e["row_panel_kernels"]["frac_of_unscaled_fp8_mfma_rate_2p5pf"] = t / 2500.0
@@ -82,6 +89,7 @@ for name, z in finals.items():
     out["engines"][name]["fidelity_vs_f32_engine"] = {"rel_l2_latents": float((z - ref).norm() / ref.norm()), "psnr_vs_f32_db": bench.psnr(img, ref_img),
                                                       "psnr_vs_hr_db": bench.psnr(img, hr01)}
 out["f32_psnr_vs_hr_db"] = bench.psnr(ref_img, hr01)
-out["psnr_diff_fp8_vs_bf16_db"] = abs(out["engines"]["fp8"]["fidelity_vs_f32_engine"]["psnr_vs_hr_db"] - out["engines"]["bf16"]["fidelity_vs_f32_engine"]["psnr_vs_hr_db"])
-out["speedup_fp8_over_bf16"] = out["engines"]["fp8"]["slices_per_s"] / out["engines"]["bf16"]["slices_per_s"]
+for name in ("fp8", "fp8_attn"):
+    out[f"psnr_diff_{name}_vs_bf16_db"] = abs(out["engines"][name]["fidelity_vs_f32_engine"]["psnr_vs_hr_db"] - out["engines"]["bf16"]["fidelity_vs_f32_engine"]["psnr_vs_hr_db"])
+    out[f"speedup_{name}_over_bf16"] = out["engines"][name]["slices_per_s"] / out["engines"]["bf16"]["slices_per_s"]
 print(json.dumps(out))

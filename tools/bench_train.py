@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--train-adapter", action="store_true", help="BASELINE config 3 in full: Adapter_XL(sk=True, cin=192) on [B,3,256,256] "
                                                                   "runs AND trains every step (233.7 M more parameters, 935 MB gradient bucket)")
     ap.add_argument("--profile", action="store_true", help="per-kernel-class HIP-event profile of one step")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] training leg: forward through the fp8 projections + fp8 attention "
+                                                       "(fp8_train), backward in bf16")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -67,7 +69,8 @@ def main():
     cfg = mrisr.UNetConfig()
     sd = P.random_state_dict(P.unet_param_shapes(cfg), 20260501, dev)  # same weights on every rank
     sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), 20260504, dev))
-    unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype, lora_rank=4, lora_alpha=4, lora_fused=True)
+    f8 = dict(fp8=True, fp8_attention=True, fp8_train=True) if args.fp8 else {}
+    unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype, lora_rank=4, lora_alpha=4, lora_fused=True, **f8)
     unet.load_state_dict(sd)
     tr = mrisr.LoRATrainer(unet, lr=1e-4)
     B, h = args.batch, args.latent
@@ -115,7 +118,7 @@ def main():
     losses.append(float(loss))
     out = {"metric": "lora_finetune_samples_per_s", "value": round(world * B * args.steps / el, 3), "unit": "samples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
-           "dtype": args.dtype, "data": "synthetic", "losses": [round(v, 5) for v in losses],
+           "dtype": args.dtype + (" (fp8 e4m3 forward: K=320 projections + attention; bf16 backward)" if args.fp8 else ""), "data": "synthetic", "losses": [round(v, 5) for v in losses],
            "workspace_GiB": round(unet.workspace_bytes / 2**30, 2),
            "config": {"workload": f"SD-1.5 UNet + LoRA r=4 fine-tune step, [{B},4,{h},{h}] per GPU, all-reduce of "
                                   f"{tr.num_trainable} f32 grads" + (f" + trainable Adapter_XL ({atr.num_trainable} f32 grads)" if atr else ""),

@@ -269,6 +269,17 @@ static int launch_dpad(const AttnArgs& a, hipStream_t st) {
                  2.0 * BH * (2.0 * a.nq * a.hd + 2.0 * a.nk * a.hd), st);
     // ONES: the row sum rides along the P.V product as row `hd` of V^T - needs a spare row in the last 16-row block
     const bool ones = a.hd < DB * 16;
+    // QF = 4 (a wave owns 64 queries): every K / V^T fragment read from LDS serves twice the MFMAs - the fp8 kernel, whose only
+    // difference in the key loop is half the LDS bytes, runs 17 % faster than this one, so the loop is not purely VALU bound.
+    // Only where the registers allow it (head dims up to 64) and enough query blocks remain (MRISR_ATTN_QF4=0: off).
+    static const int qf4_env = [] { const char* e = getenv("MRISR_ATTN_QF4"); return e ? atoi(e) : 1; }();
+    if constexpr (DPAD <= 64) {
+        if (qf4_env && a.nq >= 512 && a.nk >= 256 && ones) {  // (77-key cross-attention: 25.0 -> 26.2 us with QF = 4; self-attention at N = 1024: 85.3 -> 78.3 us)
+            hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 4, true>), dim3((a.nq + 255) / 256, BH), dim3(256), 0, st, a);
+            MRISR_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (a.nq >= 128) {
         if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 2, true>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 2, false>), dim3((a.nq + 127) / 128, BH), dim3(256), 0, st, a);

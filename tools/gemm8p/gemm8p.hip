@@ -47,6 +47,17 @@ constexpr int HALF = 128 * BK * 2;     // one half-tile: 128 rows x 128 B = 16 K
 constexpr int TILE = 4 * HALF;         // one K tile: A0h A1h B0h B1h
 constexpr int LDS_BYTES = 2 * TILE;    // 128 KiB
 
+// 16-byte slot swizzle of a 128-byte LDS row.  SWZ16 = 1: slot ^ ((row >> 1) & 7) - the 16 lanes of a ds_read_b128 group (16 consecutive rows, one
+// k-chunk) land on 16 distinct 16-byte slots of the 256-byte bank row (two LDS rows per bank row: the row's parity picks the half, (row >> 1) & 7
+// the slot): conflict-free.  SWZ16 = 0: slot ^ (row & 7) - rows r and r + 8 share a slot: 2-way conflict per group (what the library's kernels use).
+#ifndef SWZ16
+#define SWZ16 1
+#endif
+#if SWZ16
+#define SWZ(row) (((row) >> 1) & 7)
+#else
+#define SWZ(row) ((row) & 7)
+#endif
 #ifndef SETPRIO
 #define SETPRIO 1
 #endif
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16* __restrict__ A,
     // ---- stage geometry: half-tile chunk c = tid + 512 i (i = 0, 1): LDS byte c * 16; row = c >> 3, slot = c & 7 holds source k-chunk slot ^ (row & 7)
     // per-lane part: (row * K + kc * 8) * 2 with row = tid >> 3 - the SAME for A and B, for both halves and for the second chunk
     // (row + 64: same row & 7); everything else - tile origin, half, second chunk, K tile - is a scalar offset
-    const unsigned vo = (unsigned)((((size_t)(tid >> 3)) * K + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2);
+    const unsigned vo = (unsigned)((((size_t)(tid >> 3)) * K + (((tid & 7) ^ SWZ(tid >> 3)) * 8)) * 2);
     const unsigned sa0 = (unsigned)((size_t)m0 * K * 2), sb0 = (unsigned)((size_t)n0 * K * 2);
     const unsigned s64 = (unsigned)((size_t)64 * K * 2), s128 = 2 * s64;
     const int nkt = K / BK;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16* __restrict__ A,
     bf16x8 Ax[4][2], Ay[4][2], B0[2][2], B1[2][2];  // [block][k-step]
     const int a_base = wr * HALF + fr * 128;
     const int b_base = (2 + (wc >> 1)) * HALF + ((wc & 1) * 64 + fr) * 128;
-    const int sw0 = ((0 * 4 + fg) ^ (fr & 7)) * 16, sw1 = ((1 * 4 + fg) ^ (fr & 7)) * 16;  // (row & 7) == (fr & 7): blocks are 16-row aligned
+    const int sw0 = ((0 * 4 + fg) ^ SWZ(fr)) * 16, sw1 = ((1 * 4 + fg) ^ SWZ(fr)) * 16;  // SWZ(row) == SWZ(fr): blocks are 16-row aligned
     auto read_a = [&](bf16x8 (&dst)[4][2], int buf, int mh) {
         const char* p = smem + buf * TILE + a_base + mh * 64 * 128;
 #pragma unroll
@@ -157,7 +168,76 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16* __restrict__ A,
 
     // phase position pos = 0..7 inside an (even, odd) K-tile pair starting at T: stage item sigma = 4 T + pos + 7.  nkt is even;
     // the reads issued in the last two phases of the last pair fetch a K tile that does not exist (unused registers).
-    if constexpr (STAGGER == 0) {
+    if constexpr (STAGGER == 2) {
+    // ---- LONG-INTERVAL staggered form: ONE L and ONE M interval per K tile.  L(T): all 24 fragment reads of K tile T (16 A + 8 B:
+    // 96 VGPRs - no second register set: inside a wave L and M alternate, only the two wave GROUPS overlap); M(T): 64 MFMAs = 1,024
+    // cycles of the SIMD's matrix pipe.  Group g runs L(T) in interval 2T + g and M(T) in 2T + g + 1, so in every interval one wave of
+    // each SIMD streams MFMAs while the other reads LDS; two barriers per K tile instead of eight.
+    //   * K tile T + 1 goes into the buffer K tile T - 1 was read from (last reads: group 1, interval 2T - 1): BOTH groups issue their
+    //     share of it in interval 2T (group 0 at the start of L(T), group 1 at the start of M(T - 1)) and BOTH wait for it at the end of
+    //     interval 2T + 1 (group 0: end of M(T), group 1: end of L(T)) - nothing younger is in flight then, so the wait is vmcnt(0), one
+    //     barrier interval after the issue; the reads follow in intervals 2T + 2 (g = 0) and 2T + 3 (g = 1).
+    bf16x8 Af[8][2], Bf[4][2];
+    auto read_all = [&](int buf) {
+        const char* pa = smem + buf * TILE + a_base;
+        const char* pb = smem + buf * TILE + b_base;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            Bf[nb][0] = *reinterpret_cast<const bf16x8*>(pb + nb * 16 * 128 + sw0);
+            Bf[nb][1] = *reinterpret_cast<const bf16x8*>(pb + nb * 16 * 128 + sw1);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            Af[mb][0] = *reinterpret_cast<const bf16x8*>(pa + mb * 16 * 128 + sw0);
+            Af[mb][1] = *reinterpret_cast<const bf16x8*>(pa + mb * 16 * 128 + sw1);
+        }
+    };
+    auto mma_all = [&]() {
+#if SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mb >> 2][nb >> 1][mb & 3][nb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[nb][kk], Af[mb][kk], acc[mb >> 2][nb >> 1][mb & 3][nb & 1], 0, 0, 0);
+#if SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    auto stage_tile = [&](int U) { stage(JC(0), U); stage(JC(1), U); stage(JC(2), U); stage(JC(3), U); };
+    const bool g1 = wr == 1;
+    // (the generic prologue above staged K tile 0 and three items of K tile 1 and read phase-0 fragments this form does not use:
+    //  re-stage K tile 1 whole - same data into the same, unread buffer - and drain)
+    stage_tile(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // interval "-1" for group 1 (it starts one interval late); K tiles 0 and 1 are resident, so the first stage is K tile 2 in interval 2
+    if (g1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int T = 0; T < nkt; ++T) {
+        const int buf = T & 1;
+        // ---- L(T) ----
+        if (!g1 && T >= 1) stage_tile(T + 1);              // group 0: interval 2T (K tile T - 1's buffer is free since interval 2T)
+        read_all(buf);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (g1 && T >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 1: end of interval 2T + 1: K tile T + 1 has landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M(T) ----
+        if (g1) stage_tile(T + 2);                          // group 1: interval 2T + 2 = 2(T + 1): its share of K tile T + 2
+        __builtin_amdgcn_sched_barrier(0);
+        mma_all();
+        if (!g1 && T >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0: end of interval 2T + 1
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
+    } else if constexpr (STAGGER == 0) {
     for (int T = 0; T < nkt; T += 2) {
         // ===== even K tile T (LDS buffer 0): (0,0) (0,1) (1,1) (1,0) =====
         PHASE_HEAD(0)
@@ -265,8 +345,8 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
     const int iters = argc > 4 ? atoi(argv[4]) : 20;
     const int zero = argc > 5 ? atoi(argv[5]) : 0;  // 1: zero-filled operands (the guide's other figure)
-    const int stagger = argc > 6 ? atoi(argv[6]) : 1;  // 1: the two wave groups run one barrier interval apart (default)
-    auto kern = stagger ? gemm8p_kernel<1> : gemm8p_kernel<0>;
+    const int stagger = argc > 6 ? atoi(argv[6]) : 2;  // 0: all waves in step; 1: 8-phase, groups one interval apart; 2: one L + one M interval per K tile (default)
+    auto kern = stagger == 2 ? gemm8p_kernel<2> : (stagger ? gemm8p_kernel<1> : gemm8p_kernel<0>);
     if (M % BM || N % BN || K % (2 * BK) || K < 4 * BK) { fprintf(stderr, "M, N multiples of 256; K a multiple of 128, >= 256\n"); return 2; }
     std::vector<unsigned short> hA((size_t)M * K), hB((size_t)N * K), hC((size_t)M * N);
     unsigned s = 12345u;
@@ -307,8 +387,8 @@ int main(int argc, char** argv) {
         ms /= iters; tot += ms; if (ms < best) best = ms;
     }
     const double fl = 2.0 * M * N * (double)K;
-    printf("{\"kernel\": \"gemm8p 256x256x64 8-wave 8-phase\", \"M\": %d, \"N\": %d, \"K\": %d, \"operands\": \"%s\", \"setprio\": %d, \"stagger\": %d, \"rel_err\": %.3e, \"max_abs_err\": %.3e, "
+    printf("{\"kernel\": \"gemm8p 256x256x64 8-wave 8-phase\", \"M\": %d, \"N\": %d, \"K\": %d, \"operands\": \"%s\", \"setprio\": %d, \"swz16\": %d, \"stagger\": %d, \"rel_err\": %.3e, \"max_abs_err\": %.3e, "
            "\"us_best\": %.2f, \"us_mean\": %.2f, \"tflops_best\": %.1f, \"tflops_mean\": %.1f, \"frac_of_2p5pf\": %.3f}\n",
-           M, N, K, zero ? "zero" : "uniform[-1,1)", SETPRIO, stagger, relerr, worst, best * 1e3, tot / 5 * 1e3, fl / best / 1e9, fl / (tot / 5) / 1e9, fl / (tot / 5) / 1e9 / 2500.0);
+           M, N, K, zero ? "zero" : "uniform[-1,1)", SETPRIO, SWZ16, stagger, relerr, worst, best * 1e3, tot / 5 * 1e3, fl / best / 1e9, fl / (tot / 5) / 1e9, fl / (tot / 5) / 1e9 / 2500.0);
     return relerr < 1e-2 ? 0 : 1;
 }

@@ -237,6 +237,13 @@ int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_ten
 /* Gradients w.r.t. the T2I-Adapter features (intrablock[i] of the following mrisr_train_step calls) are written to
  * grads[i] (same shapes; NCHW f32/bf16 or NHWC compute dtype) for the adapter's own backward; n = 0 switches it off. */
 int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, int n);
+/* ControlNet residuals for the following mrisr_train_step calls (reference call shape: unet(..., down_block_additional_residuals=down_res,
+ * mid_block_additional_residual=mid_res), src/adapters/res_srdiff.py:73-78, inside the training graph): down[k] / mid are added to the skips /
+ * the mid block's output (out of place, as diffusers does), and d(loss)/d(down[k]), d(loss)/d(mid) are written to d_down[k] / d_mid (same
+ * shapes; may be null) - the seeds of the ControlNet's own backward (mrisr_controlnet_train_step).  n_down = 0, mid = NULL switches it off.
+ * The UNet may be frozen (lora_rank 0: mrisr_train_bind(m, NULL, NULL, 0, stream)): the step then only computes these input gradients. */
+int mrisr_train_set_controlnet_residuals(mrisr_model* m, const mrisr_tensor* down, const mrisr_tensor* d_down, int n_down,
+                                         const mrisr_tensor* mid, const mrisr_tensor* d_mid);
 int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream);
 /* ema = decay * ema + (1 - decay) * theta  (diffusers EMAModel.step on the flat trainable vector) */
 int mrisr_optim_ema(float* ema_dev, const float* theta_dev, int64_t n, float decay, void* stream);

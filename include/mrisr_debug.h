@@ -40,6 +40,10 @@ int mrisr_bench_gemm(int M, int N, int K, int conv, int B, int H, int W, int str
  * -1 (default) as MRISR_SK_INKERNEL says (unset: the reduce kernel - measured no slower, see gemm.hip sk_counters_for) */
 void mrisr_debug_sk_inkernel(int on);
 
+/* the sub-pixel form of the decoder's `nearest x2 -> conv3x3` layers (bf16 inference): -1 default (MRISR_SUBPIX, 2048 low-resolution
+ * rows), 0 off (the literal up-sampled conv), n > 0: from n rows on */
+void mrisr_debug_subpix(int min_rows);
+
 /* micro-benchmark of the fused feed-forward kernel (tools/mlp_probe.py): M rows of width 320, random operands */
 int mrisr_bench_mlp(int M, int hidden, int iters, float* ms_out);
 

@@ -918,6 +918,24 @@ static int op_conv3x3_t(const mrisr_tensor* x, const mrisr_tensor* x2, const flo
         MRISR_CHECK_HIP(hipStreamSynchronize(st));
         return 0;
     }
+    if (ups == 2) {  // the sub-pixel form of `nearest x2 -> conv3x3` (runner.h::upsample_conv): four 2 x 2 parity convs + interleave
+        MRISR_REQUIRE(sizeof(T) == 2 && !x2 && stride == 1 && act == ACT_NONE && (4 * Cin) % 64 == 0 && cout % 8 == 0, "sub-pixel upsample conv: bf16, single source");
+        MRISR_REQUIRE(y->shape[1] == cout && y->shape[2] == 2 * H && y->shape[3] == 2 * W, "conv output shape");
+        DevBuf sp, planes;
+        TRY(sp.reserve((size_t)16 * cout * Cin * sizeof(T), false));
+        TRY(planes.reserve((size_t)4 * B * H * W * cout * sizeof(T), false));
+        TRY(launch_pack_conv_subpix<T>(w, sp.p, cout, Cin, st));
+        GemmArgs g;
+        g.a0 = x->data; g.c0 = C0; g.lda0 = C0;
+        g.conv = 1; g.B = B; g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1;
+        g.kw = 2; g.subpix = 1; g.batch = 4; g.w_bs = (long long)cout * 4 * Cin; g.o_bs = (long long)B * H * W * cout;
+        g.w = sp.p; g.M = B * H * W; g.N = cout; g.K = 4 * Cin; g.bias = bias; g.out = planes.p; g.ldo = cout;
+        TRY(gemm_choose(g, true));
+        TRY(launch_gemm<T>(g, st));
+        TRY(launch_subpix_shuffle<T>(planes.p, y->data, B, H, W, cout, st));
+        MRISR_CHECK_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
     GemmArgs g;
     g.a0 = x->data; g.c0 = C0; g.lda0 = C0;
     if (x2) { g.a1 = x2->data; g.c1 = C1; g.lda1 = C1; }
@@ -1418,6 +1436,17 @@ int mrisr_train_step(mrisr_model* m, const mrisr_tensor* sample, const mrisr_ten
 int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, int n) {
     MRISR_REQUIRE(m && n >= 0 && n <= 4 && (n == 0 || grads), "feature-gradient outputs: 0..4 tensors");
     m->d_intra.assign(grads, grads + n);
+    return 0;
+}
+int mrisr_train_set_controlnet_residuals(mrisr_model* m, const mrisr_tensor* down, const mrisr_tensor* d_down, int n_down,
+                                         const mrisr_tensor* mid, const mrisr_tensor* d_mid) {
+    MRISR_REQUIRE(m && n_down >= 0 && n_down <= 16 && (n_down == 0 || down), "ControlNet residuals of the training step: 0..16 tensors");
+    m->tr_down.assign(down, down + n_down);
+    if (d_down) m->d_tr_down.assign(d_down, d_down + n_down); else m->d_tr_down.clear();
+    m->has_tr_mid = mid != nullptr;
+    m->tr_mid = mid ? *mid : mrisr_tensor{};
+    m->d_tr_mid = d_mid ? *d_mid : mrisr_tensor{};
+    m->train_ws_key.clear();  // the training workspace is planned per residual configuration
     return 0;
 }
 int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream) {

@@ -93,6 +93,9 @@ struct GemmArgs {
     const void* w = nullptr;
     int M = 0, N = 0, K = 0;
     // ---- batching (blockIdx.z): element offsets ----
+    // sub-pixel form of `nearest x2 -> 3x3 conv` (runner.h::upsample_conv): kw = 2 taps per kernel row (K = kw * kw * C), and with
+    // subpix the batch index z is the output parity (py, px) = (z >> 1, z & 1): the 2 x 2 window starts at (oy - pad + py, ox - pad + px)
+    int kw = 3, subpix = 0;
     int batch = 1;
     long long a_bs = 0, w_bs = 0;
     int heads = 1;             // output offset = (z / heads) * o_bs + (z % heads) * o_hs
@@ -339,6 +342,12 @@ int launch_pack_rows(const float* src, int rows, int cols, void* dst, int ld_dst
 // conv weight [Cout][Cin][3][3] f32 -> [Cout][ky][kx][Cin] T
 template <typename T>
 int launch_pack_conv3x3(const float* src, void* dst, int Cout, int Cin, int ks, hipStream_t st);
+// `nearest x2 -> conv3x3` as four 2 x 2 convs on the low-resolution input (one per output parity): dst [4][Cout][2][2][Cin], every tap
+// the f32 sum of the 3 x 3 taps that read the same low-resolution pixel; and the pass that interleaves the four parity planes
+template <typename T>
+int launch_pack_conv_subpix(const float* src, void* dst, int Cout, int Cin, hipStream_t st);
+template <typename T>
+int launch_subpix_shuffle(const void* planes, void* out, int B, int H, int W, int C, hipStream_t st);
 template <typename T>
 int launch_pack_conv3x3_padded(const float* src, void* dst, int Cout, int Cin, int ks, int Cout_pad, int Cin_pad, hipStream_t st);
 int launch_pack_bias_geglu(const float* src, float* dst, int half, hipStream_t st);

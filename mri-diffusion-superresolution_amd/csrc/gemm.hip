@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -748,8 +749,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             const int rem = m - b * hw;
             const int oy = rem / g.Wout;
             ab[it] = b * g.Hin;
-            ay[it] = oy * g.stride - g.pad;
-            ax[it] = (rem - oy * g.Wout) * g.stride - g.pad;
+            ay[it] = oy * g.stride - g.pad + (g.subpix ? (z >> 1) : 0);  // sub-pixel up-sampling: the window of parity (py, px) starts py / px later
+            ax[it] = (rem - oy * g.Wout) * g.stride - g.pad + (g.subpix ? (z & 1) : 0);
         }
     }
     const int acb = pch * 16;  // physical chunk byte offset is applied through `c` below for conv rows
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             const int key = tap * 2 + (second ? 1 : 0);
             if (key != seg_key) {  // new (tap, source) segment: refresh the per-lane offsets (uniform branch)
                 seg_key = key;
-                const int ky = tap / 3, kx = tap - ky * 3;
+                const int ky = g.kw == 3 ? tap / 3 : tap / g.kw, kx = tap - ky * g.kw;
                 const int ld = second ? g.lda1 : g.lda0;
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
@@ -2994,6 +2995,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
     char key[200];
     snprintf(key, sizeof(key), "%d,%d,%d,c%d,s%d,u%d,%d,%d,a%d,o%d,b%d,r%d,v%d,h%d,w%d", g0.M, g0.N, g0.K, g0.conv, g0.stride + 8 * (1 - g0.pad), g0.ups, g0.c0,
              g0.c1, g0.act, g0.out_mode, g0.batch, g0.resid ? 1 : 0, g0.rowvec ? 1 : 0, g0.Hin, g0.Win);
+    if (g0.kw != 3 || g0.subpix) snprintf(key + strlen(key), sizeof(key) - strlen(key), ",q%d", g0.kw * 2 + g0.subpix);  // (older tables have no such keys)
     static bool cache_loaded = false;
     const char* cache_path = getenv("MRISR_TUNE_CACHE");  // optional on-disk table: "key<TAB>tile<TAB>split" per line
     if (!cache_loaded) {
@@ -3065,7 +3067,7 @@ static int tune(const GemmArgs& g0, int* tile_out, int* split_out) {
         if ((tile == 25 || tile == 26 || tile == 27 || tile == 31) && g.act == ACT_GEGLU) continue;
         if (deep && t128 >= 2048) continue;  // plenty of workgroups per CU: the 2-stage structure wins (sweep)
         for (int s = 1; s <= 32; s *= 2) {
-            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50 || (tile >= 32 && tile <= 39))) break;
+            if (s > 1 && (g.act == ACT_GEGLU || nkt / s < 4 || t128 * s > 4096 || tile >= 50 || (tile >= 32 && tile <= 39) || g.kw != 3 || g.subpix)) break;
             const size_t pbytes = s > 1 ? (size_t)s * g.M * g.N * 4 * zb : 0;
             if (pbytes > ((size_t)1 << 30)) break;
             if (s > 1 && g_ts.reserve(4, pbytes, false)) return 1;
@@ -3119,6 +3121,8 @@ extern "C" void mrisr_debug_gemm_flags(int f) { g_gemm_flags = f; }
 static int gemm_flags_now() { return g_gemm_flags; }
 // tools/table_search.py: overrides one entry of the tile table in this process (key as in the table file)
 extern "C" void mrisr_debug_set_tuned(const char* key, int tile, int split) { g_tuned[key] = {tile, split}; }
+int g_subpix_override = -1;
+extern "C" void mrisr_debug_subpix(int min_rows) { g_subpix_override = min_rows; }
 static int g_prefer_tile = 0;  // test hook: use this specialised kernel (halo 41-45 / weight-stationary 50-52) wherever it is eligible
 extern "C" void mrisr_debug_prefer_tile(int t) { g_prefer_tile = t; }
 
@@ -3206,14 +3210,19 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     MRISR_REQUIRE(g.splitk == 1 || g.partial != nullptr, "split-K needs a partial buffer");
     MRISR_REQUIRE(g.splitk == 1 || g.act != ACT_GEGLU, "GEGLU epilogue cannot be split");
     MRISR_REQUIRE(zero_page() != nullptr, "zero page not initialised");
-    if (g.conv) MRISR_REQUIRE(g.K == 9 * (g.c0 + g.c1), "conv K");
-    else MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K");
+    if (g.conv) { MRISR_REQUIRE(g.K == g.kw * g.kw * (g.c0 + g.c1) && (g.kw == 3 || g.kw == 2), "conv K"); }
+    else { MRISR_REQUIRE(g.K == g.c0 + g.c1, "plain K"); }
+    if (g.kw != 3 || g.subpix) {
+        MRISR_REQUIRE(sizeof(T) == 2 && g.conv && !g.c1 && g.stride == 1 && !g.ups && !g.zstuff && g.splitk == 1 && (!g.subpix || g.batch == 4),
+                      "2 x 2 / sub-pixel conv: bf16 buffer-addressed kernels, single source, stride 1, un-split, four parity batches");
+    }
     static const int stage_env = [] { const char* e = getenv("MRISR_STAGE_OUT"); return e ? atoi(e) : 2; }();  // 0 off, 1 tiled kernels, 2 + halo kernels (default), 3: as 2 but residual added before staging
     const_cast<GemmArgs&>(g).stage_out = stage_env;
     const_cast<GemmArgs&>(g).dbg = g_gemm_flags;
     int tile = g.tile ? g.tile : g_force_tile, s = g.splitk;
     if (!tile) plan(g, sizeof(T) == 2, g.splitk, &tile, &s);
     if ((sizeof(T) != 2 || !bl_ok(g)) && tile > 4) tile = 1;
+    if ((g.kw != 3 || g.subpix) && !(tile >= 14 && tile <= 31)) tile = 25;  // only gemm_bl_kernel's gather knows these forms
     // split-K: the bf16 DMA kernels (tiled and halo) finish the reduction themselves
     {   // cold-weight pre-touch: matrices of at least MRISR_PRETOUCH_MIN_KB (default 512; 0 ... 1024 measure the same); MRISR_PRETOUCH=0 turns it off
         static const int on = [] { const char* e = getenv("MRISR_PRETOUCH"); return e ? atoi(e) : 1; }();

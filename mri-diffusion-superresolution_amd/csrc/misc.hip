@@ -718,6 +718,63 @@ int launch_pack_conv3x3(const float* src, void* dst, int Cout, int Cin, int ks, 
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
+// ---- sub-pixel decomposition of `nearest x2 -> conv3x3` -----------------------------------------------------------------------
+// Output pixel (2y + py, 2x + px) reads the up-sampled rows 2y + py + dy, dy = -1, 0, 1, i.e. the low-resolution rows
+//   py = 0:  y - 1 (dy = -1),  y (dy = 0, +1)            py = 1:  y (dy = -1, 0),  y + 1 (dy = +1)
+// (zero padding of the up-sampled image = out-of-range low-resolution rows, exactly) - a 2 x 2 window starting at y - 1 + py whose
+// tap t = 0 / 1 carries the sum of the 3 x 3 taps {0} / {1, 2} (py = 0) or {0, 1} / {2} (py = 1); the same along x.  4/9 of the MACs.
+template <typename T>
+__global__ void pack_conv_subpix_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cout, int Cin) {
+    const long long per = (long long)Cout * 4 * Cin;  // one parity's bank [Cout][2][2][Cin]
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < 4 * per; i += (long long)gridDim.x * 256) {
+        const int par = (int)(i / per);
+        const long long j = i - par * per;
+        const int c = (int)(j % Cin);
+        const int t = (int)((j / Cin) % 4);
+        const int n = (int)(j / (4ll * Cin));
+        const int py = par >> 1, px = par & 1, ty = t >> 1, tx = t & 1;
+        // 3 x 3 taps folded into low-resolution tap (ty, tx): k0 .. k1 inclusive
+        const int ky0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int kx0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        float acc = 0.f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) acc += src[((size_t)n * Cin + c) * 9 + ky * 3 + kx];
+        dst[i] = from_f32<T>(acc);
+    }
+}
+template <typename T>
+int launch_pack_conv_subpix(const float* src, void* dst, int Cout, int Cin, hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv_subpix_kernel<T>, dim3(nblocks(16ll * Cout * Cin)), dim3(256), 0, st, src, reinterpret_cast<T*>(dst), Cout, Cin);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// planes [4][B][H][W][C] (parity-major) -> out [B][2H][2W][C]; 16-byte pieces, one output pixel row of C channels per group of C/8 threads
+template <typename T>
+__global__ void subpix_shuffle_kernel(const T* __restrict__ planes, T* __restrict__ out, int B, int H, int W, int C) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int cv = C / VE;
+    const long long total = (long long)B * 4 * H * W * cv;
+    const long long plane = (long long)B * H * W * C;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i % cv);
+        long long p = i / cv;                 // output pixel index (b, Y, X)
+        const int X = (int)(p % (2 * W)); p /= 2 * W;
+        const int Y = (int)(p % (2 * H));
+        const int b = (int)(p / (2 * H));
+        const int par = (Y & 1) * 2 + (X & 1);
+        const long long src = par * plane + (((long long)b * H + (Y >> 1)) * W + (X >> 1)) * C + (long long)v * VE;
+        *reinterpret_cast<uint4*>(out + i * VE) = *reinterpret_cast<const uint4*>(planes + src);
+    }
+}
+template <typename T>
+int launch_subpix_shuffle(const void* planes, void* out, int B, int H, int W, int C, hipStream_t st) {
+    MRISR_REQUIRE(C % (16 / (int)sizeof(T)) == 0, "sub-pixel shuffle: channel count must fill 16-byte pieces");
+    ProfScope ps("subpix_shuffle", 0.0, 2.0 * 4.0 * B * H * W * C * sizeof(T), st);
+    hipLaunchKernelGGL(subpix_shuffle_kernel<T>, dim3(nblocks(4ll * B * H * W * C / (16 / (int)sizeof(T)))), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(planes), reinterpret_cast<T*>(out), B, H, W, C);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 __global__ void pack_bias_geglu_kernel(const float* src, float* dst, int half) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= 2 * half) return;
@@ -867,6 +924,8 @@ int launch_quant_rows_fp8(const void* src_bf16, int rows, int cols, void* dst8, 
     template int launch_pack_rows<T>(const float*, int, int, void*, int, int, int, int, int, float, hipStream_t);  \
     template int launch_pack_conv3x3<T>(const float*, void*, int, int, int, hipStream_t);                          \
     template int launch_pack_conv3x3_padded<T>(const float*, void*, int, int, int, int, int, hipStream_t);         \
+    template int launch_pack_conv_subpix<T>(const float*, void*, int, int, hipStream_t);                            \
+    template int launch_subpix_shuffle<T>(const void*, void*, int, int, int, int, hipStream_t);                     \
     template int launch_fill_zero<T>(void*, long long, hipStream_t);
 INST(float)
 INST(bf16)

@@ -24,6 +24,7 @@ struct Level {
     std::vector<XfW> xf;
     bool has_down = false, has_up = false;
     ConvW down, up;
+    void* up_sp = nullptr;  // bf16 inference: `up` as four 2 x 2 parity banks [4][cout][2][2][cin] (sub-pixel form, launch_pack_conv_subpix)
 };
 struct HeadBuf {  // head-major q / k / v^T staging for one (tokens, channels) geometry; pads stay zero
     int B = 0, H = 0, N = 0, hd = 0, npad = 0, dpad = 0;
@@ -100,6 +101,10 @@ struct Model {
     float* grad = nullptr;               // caller-owned flat f32 gradient vector (bound)
     bool train_ready = false;
     std::vector<mrisr_tensor> d_intra;   // optional outputs: gradients w.r.t. the T2I-Adapter features of the next train_step
+    // ControlNet residuals of the next train_step (inputs) and the tensors their gradients are written to (outputs): 12 + mid
+    std::vector<mrisr_tensor> tr_down, d_tr_down;
+    mrisr_tensor tr_mid{}, d_tr_mid{};
+    bool has_tr_mid = false;
     std::string train_ws_key;
     std::vector<LinW*> lora_linears();   // every LinW that carries adapters, fixed order
     int train_prepare(hipStream_t st);   // dgrad weight copies + trainable layout (after finalize)

@@ -316,6 +316,13 @@ static int finalize_t(Model& m, hipStream_t st) {
             if (i < L - 1) {
                 lv.has_up = true;
                 lv.up = pk.conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
+                // the sub-pixel form of `nearest x2 -> conv3x3` (4/9 of the MACs): bf16 engine, channel counts that fill K tiles
+                if (sizeof(T) == 2 && lv.up.w && lv.up.ks == 3 && (4 * lv.up.cin) % 64 == 0 && lv.up.cout % 8 == 0) {
+                    const RawParam* w = m.find(lv.up.name + ".weight");
+                    lv.up_sp = m.new_packed((size_t)16 * lv.up.cout * lv.up.cin * sizeof(T), false);
+                    if (!lv.up_sp || !w) pk.err = 4;
+                    else if (launch_pack_conv_subpix<T>(static_cast<const float*>(w->data->p), lv.up_sp, lv.up.cout, lv.up.cin, st)) pk.err = 5;
+                }
             }
             m.up.push_back(std::move(lv));
         }

@@ -9,6 +9,8 @@
 
 namespace mrisr {
 
+extern int g_subpix_override;  // test hook (mrisr_debug_subpix): -1 = MRISR_SUBPIX / default, 0 = off, n = minimum low-resolution rows
+
 #ifndef TRY
 #define TRY(expr)              \
     do {                       \
@@ -99,6 +101,40 @@ struct Runner {
         if (resid) { g.resid = resid->p; g.ldr = resid->C; }
         g.out = out->p; g.ldo = cw.cout;
         return run_gemm(g);
+    }
+
+    // Upsample2D: nearest x2, then conv3x3 (diffusers).  Every output pixel (2y + py, 2x + px) reads only a
+    // 2 x 2 window of the LOW-resolution input (the three up-sampled rows it touches are two input rows), so the layer is four 2 x 2
+    // convs - one per output parity, filter taps pre-summed at load (launch_pack_conv_subpix) - at 4/9 of the MACs: one batched implicit
+    // GEMM (z = parity: its own bank, its own window origin; M = B h w rows each) into four parity planes, then one interleaving pass.
+    // bf16 inference only (the f32 parity engine and the training graph keep the literal form); MRISR_SUBPIX=0 / a minimum row count.
+    static int subpix_min_rows() {
+        static const int v = [] { const char* e = getenv("MRISR_SUBPIX"); return e ? atoi(e) : 2048; }();  // 0: off; n: from n low-resolution rows on
+        return g_subpix_override >= 0 ? g_subpix_override : v;
+    }
+    int upsample_conv(const Act& x, const Level& lv, Act* out) {
+        const int minr = subpix_min_rows();
+        if (!(sizeof(T) == 2 && lv.up_sp && !m.keep && minr > 0 && (long long)x.rows() >= minr))
+            return conv3(x, nullptr, lv.up, 1, 1, nullptr, 0, 1, nullptr, ACT_NONE, out);
+        const ConvW& cw = lv.up;
+        MRISR_REQUIRE(cw.cin == x.C, "upsampler weight mismatch");
+        *out = new_act(x.B, 2 * x.H, 2 * x.W, cw.cout);
+        if (!out->p) return 7;
+        const size_t mk = m.arena.mark();
+        const long long plane = (long long)x.rows() * cw.cout;
+        T* planes = static_cast<T*>(alloc((size_t)4 * plane * sizeof(T)));
+        if (!planes) return 7;
+        GemmArgs g;
+        g.a0 = x.p; g.c0 = x.C; g.lda0 = x.C;
+        g.conv = 1; g.B = x.B; g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W; g.stride = 1; g.ups = 0;
+        g.kw = 2; g.subpix = 1; g.batch = 4; g.a_bs = 0; g.w_bs = (long long)cw.cout * 4 * cw.cin; g.o_bs = plane;
+        g.w = lv.up_sp; g.M = (int)x.rows(); g.N = cw.cout; g.K = 4 * x.C; g.bias = cw.b;
+        g.out = planes; g.ldo = cw.cout;
+        g.alg_flops = 2.0 * 4.0 * g.M * (double)g.N * g.K;
+        TRY(run_gemm(g));
+        if (!dry) TRY(launch_subpix_shuffle<T>(planes, out->p, x.B, x.H, x.W, cw.cout, st));
+        m.arena.release(mk);
+        return 0;
     }
 
     // y[M][n] = x[M][k] W^T (+LoRA tail) + bias ...; x given as raw rows
@@ -497,7 +533,7 @@ struct Runner {
             }
             if (lv.has_up) {
                 Act y;
-                TRY(conv3(x, nullptr, lv.up, 1, 1, nullptr, 0, 1, nullptr, ACT_NONE, &y));
+                TRY(upsample_conv(x, lv, &y));
                 x = y;
             }
         }

@@ -141,21 +141,23 @@ static int train_prepare_t(Model& m, hipStream_t st) {
 int Model::train_prepare(hipStream_t st) {
     MRISR_REQUIRE(finalized, "call mrisr_model_finalize first");
     MRISR_REQUIRE(!is_controlnet, "the fine-tuning step is implemented for the UNet handle");
-    MRISR_REQUIRE(cfg.lora_rank > 0 && cfg.lora_fused, "fine-tuning needs explicit (un-merged) LoRA adapters");
+    // lora_rank == 0: a FROZEN UNet - the step then only differentiates with respect to its inputs (ControlNet residuals,
+    // T2I-Adapter features): no trainable vector, dX only
+    MRISR_REQUIRE(cfg.lora_rank == 0 || cfg.lora_fused, "fine-tuning needs explicit (un-merged) LoRA adapters");
     if (train_ready) return 0;
     return cfg.compute_dtype == MRISR_F32 ? train_prepare_t<float>(*this, st) : train_prepare_t<bf16>(*this, st);
 }
 
 int Model::train_bind(float* theta_dev, float* grad_dev, hipStream_t st) {
     TRY(train_prepare(st));
-    MRISR_REQUIRE(theta_dev && grad_dev, "theta / grad device buffers");
+    MRISR_REQUIRE(n_trainable == 0 || (theta_dev && grad_dev), "theta / grad device buffers");
     theta = theta_dev;
     grad = grad_dev;
     return 0;
 }
 
 int Model::lora_refresh(hipStream_t st) {
-    MRISR_REQUIRE(train_ready && theta, "bind the trainable vector first");
+    MRISR_REQUIRE(train_ready && (theta || n_trainable == 0), "bind the trainable vector first");
     for (LinW* l : lora_linears()) {
         int row0 = 0;
         for (size_t j = 0; j < l->mod_names.size(); ++j, row0 += l->secN) {
@@ -676,6 +678,37 @@ struct Trainer : Runner<T> {
         return 0;
     }
 
+    // y = copy(x) + r (a ControlNet residual, diffusers: `down_block_res_sample + down_block_additional_residual`, out of place - the
+    // encoder's own flow and its saved activations keep the un-added tensor): d(r) = d(y) -> the caller's tensor; d(x) += d(y)
+    int add_residual_t(const Act& x, const mrisr_tensor& r, const mrisr_tensor* d_out, Act* y) {
+        *y = new_act(x.B, x.H, x.W, x.C);
+        if (!y->p) return 7;
+        if (!dry) MRISR_CHECK_HIP(hipMemcpyAsync(y->p, x.p, x.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
+        TRY(R::add_external(*y, r));
+        live.insert(y->p);  // trainable upstream: the ControlNet
+        const Act yy = *y;
+        const bool x_live = is_live(x);
+        const bool want = d_out && d_out->data;
+        const mrisr_tensor out = want ? *d_out : mrisr_tensor{};
+        tape.push_back([=]() -> int {
+            auto it = slots.find(yy.p);
+            MRISR_REQUIRE(it != slots.end() && it->second.written, "residual position has no gradient");
+            Act gy = yy;
+            gy.p = it->second.g;
+            if (want) TRY(R::export_act(gy, out, 1.0f));
+            if (x_live) {
+                Slot& sx = slot(x);
+                if (!dry) {
+                    if (sx.written) TRY(launch_add_inplace<T>(sx.g, it->second.g, (long long)x.numel(), st));
+                    else MRISR_CHECK_HIP(hipMemcpyAsync(sx.g, it->second.g, x.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
+                }
+                sx.written = true;
+            }
+            return 0;
+        });
+        return 0;
+    }
+
     // dst.grad (+)= src.grad   (y = copy(x) [+ constant])
     int pass_grad(const Act& y, const Act& x) {
         if (!is_live(x)) return 0;
@@ -751,6 +784,16 @@ struct Trainer : Runner<T> {
                 TRY(export_feature_grad(x, ib++));
             }
         }
+        // ---- ControlNet residuals on the skips (after the whole down path, before the mid block: res_srdiff.py:73-78 /
+        // diffusers `down_block_res_samples = [s + r for ...]`) ----
+        if (!m.tr_down.empty()) {
+            MRISR_REQUIRE(m.tr_down.size() == skips.size(), "one ControlNet residual per skip connection");
+            for (size_t k = 0; k < skips.size(); ++k) {
+                Act y;
+                TRY(add_residual_t(skips[k], m.tr_down[k], k < m.d_tr_down.size() ? &m.d_tr_down[k] : nullptr, &y));
+                skips[k] = y;
+            }
+        }
         // ---- mid ----
         {
             Act y;
@@ -760,6 +803,10 @@ struct Trainer : Runner<T> {
             x = y;
             TRY(resnet_t(m.mid_r1, x, nullptr, &y));
             x = y;
+            if (m.has_tr_mid) {
+                TRY(add_residual_t(x, m.tr_mid, m.d_tr_mid.data ? &m.d_tr_mid : nullptr, &y));
+                x = y;
+            }
         }
         // ---- decoder ----
         for (int i = 0; i < m.cfg.num_levels; ++i) {
@@ -864,7 +911,7 @@ static int train_step_t(Model& m, const mrisr_tensor& sample, const long long* t
 
 int Model::train_step(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs, const mrisr_tensor* intrablock,
                       int n_intra, const mrisr_tensor* target, float* loss_dev, mrisr_tensor* pred_out, hipStream_t st) {
-    MRISR_REQUIRE(train_ready && theta && grad, "bind the trainable vector first (mrisr_train_bind)");
+    MRISR_REQUIRE(train_ready && (n_trainable == 0 || (theta && grad)), "bind the trainable vector first (mrisr_train_bind)");
     MRISR_REQUIRE(sample && sample->ndim == 4 && sample->shape[1] == cfg.in_channels, "sample must be [B, in_channels, h, w]");
     MRISR_REQUIRE(timestep && timestep->dtype == MRISR_I64 && timestep->ndim <= 1, "timestep: device int64, 0-dim or [B]");
     MRISR_REQUIRE(ehs && ehs->ndim == 3, "encoder_hidden_states must be [B, L, D]");

@@ -20,8 +20,9 @@ def _f32(x: Optional[torch.Tensor]):
     return None if x is None else C.c_void_p(x.detach().to(torch.float32).contiguous().data_ptr())
 
 
-def conv3x3(x, weight, bias=None, x2=None, stride=1, upsample=False, act=L.ACT_NONE, splitk=0, tile=0):
-    """x [B,C,H,W] (bf16/f32, cuda), weight [Cout,Cin,3,3] f32.  Returns NCHW tensor of x.dtype."""
+def conv3x3(x, weight, bias=None, x2=None, stride=1, upsample=False, act=L.ACT_NONE, splitk=0, tile=0, subpix=False):
+    """x [B,C,H,W] (bf16/f32, cuda), weight [Cout,Cin,3,3] f32.  Returns NCHW tensor of x.dtype.  ``upsample``: nearest x2 first
+    (diffusers Upsample2D); with ``subpix`` in its sub-pixel form (four 2 x 2 parity convs on the low-resolution input, bf16)."""
     xb, tx = _nhwc(x)
     t2 = None
     if x2 is not None:
@@ -36,7 +37,7 @@ def conv3x3(x, weight, bias=None, x2=None, stride=1, upsample=False, act=L.ACT_N
     ty = L.as_tensor(yb, L.MRISR_NHWC, shape=(B, cout, Ho, Wo))
     L.check(L.lib().mrisr_op_conv3x3(C.byref(tx), C.byref(t2) if t2 else None, C.c_void_p(w.data_ptr()),
                                      C.c_void_p(b.data_ptr()) if b is not None else None, cout, stride,
-                                     1 if upsample else 0, act, splitk, tile, C.byref(ty), L.stream_ptr()))
+                                     (2 if subpix else 1) if upsample else 0, act, splitk, tile, C.byref(ty), L.stream_ptr()))
     return yb.permute(0, 3, 1, 2)
 
 

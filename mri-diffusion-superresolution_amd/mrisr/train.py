@@ -229,8 +229,12 @@ class LoRATrainer(_FlatAdamW):
     # ---- the step, in the reference's order ----
     def forward_backward(self, noisy_latents: torch.Tensor, timesteps, encoder_hidden_states: torch.Tensor,
                          target: torch.Tensor, down_intrablock_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
-                         return_pred: bool = False, feature_grads: Optional[Sequence[torch.Tensor]] = None):
-        """loss = mse(unet(noisy_latents, timesteps, ehs), target); adds d(loss)/d(adapters) to ``self.grad``.
+                         return_pred: bool = False, feature_grads: Optional[Sequence[torch.Tensor]] = None,
+                         down_block_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
+                         mid_block_additional_residual: Optional[torch.Tensor] = None, residual_grads=None):
+        """loss = mse(unet(noisy_latents, timesteps, ehs [, ControlNet residuals] [, adapter features]), target); adds
+        d(loss)/d(adapters) to ``self.grad``.  ``residual_grads = (list of 12 tensors, mid tensor)``: d(loss)/d(each ControlNet
+        residual) is written there (the seeds of ``ControlNetTrainer.backward``).  The UNet may be frozen (``lora_rank=0``).
         Returns the loss as a device scalar (and eps_hat when ``return_pred``)."""
         u = self.unet
         x = noisy_latents.to(u.device).contiguous()
@@ -246,6 +250,16 @@ class LoRATrainer(_FlatAdamW):
         # optional: d(loss)/d(adapter features), written into the caller's tensors for the adapter's own backward
         g_arr = L.tensor_array([L.as_tensor(f) for f in (feature_grads or [])])
         L.check(L.lib().mrisr_train_set_intrablock_grads(u._h, g_arr if feature_grads else None, len(feature_grads or [])))
+        down = [r.to(u.device).contiguous() for r in (down_block_additional_residuals or [])]
+        mid = mid_block_additional_residual.to(u.device).contiguous() if mid_block_additional_residual is not None else None
+        if residual_grads is not None and (len(residual_grads[0]) != len(down) or (residual_grads[1] is None) != (mid is None)):
+            raise ValueError("residual_grads must mirror the residuals: (list like down_block_additional_residuals, tensor like mid)")
+        d_arr = L.tensor_array([L.as_tensor(r) for r in down])
+        dg_arr = L.tensor_array([L.as_tensor(r) for r in residual_grads[0]]) if residual_grads is not None else None
+        t_mid = L.as_tensor(mid) if mid is not None else None
+        t_dmid = L.as_tensor(residual_grads[1]) if (residual_grads is not None and mid is not None) else None
+        L.check(L.lib().mrisr_train_set_controlnet_residuals(u._h, d_arr if down else None, dg_arr if (down and dg_arr is not None) else None, len(down),
+                                                             C.byref(t_mid) if t_mid else None, C.byref(t_dmid) if t_dmid else None))
         L.check(L.lib().mrisr_train_step(u._h, C.byref(t_x), C.byref(t_t), C.byref(t_e), i_arr if intra else None, len(intra),
                                          C.byref(t_g), C.c_void_p(self._loss.data_ptr()), C.byref(t_p) if t_p else None,
                                          L.stream_ptr()))

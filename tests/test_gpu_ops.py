@@ -763,3 +763,65 @@ def test_unet_fp8_attention_and_fp8_training_forward():
         mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", fp8_train=True)
     with pytest.raises(ValueError):
         mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", fp8_attention=True)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(32, 640, 640, 16), (8, 1280, 1280, 8), (2, 64, 128, 8), (1, 320, 64, 12), (3, 128, 64, 5)])
+def test_upsample_conv_subpixel_form(B, Cin, Cout, H):
+    """`nearest x2 -> conv3x3` (diffusers Upsample2D in every decoder level but the last) as four 2 x 2 convs on the LOW-resolution
+    input, one per output parity, with pre-summed taps - 4/9 of the MACs, exact in exact arithmetic (borders included: the
+    up-sampled image's zero padding is the low-resolution image's).  Against F.interpolate + conv2d on the same bf16-rounded
+    operands, and against the literal up-sampled implicit GEMM it replaces; odd sizes, one image, several tile shapes."""
+    from mrisr import ops
+    x = _rnd((B, Cin, H, H), "bf16", 201)
+    w, b = _rnd((Cout, Cin, 3, 3), "f32", 202, (9 * Cin) ** -0.5), _rnd((Cout,), "f32", 203)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.to(torch.bfloat16).float(), b, padding=1)
+    lit = ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), upsample=True)
+    sub = ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), upsample=True, subpix=True)
+    assert sub.shape == ref.shape
+    # (the pre-summed taps are rounded to bf16 once instead of three / nine times: the two forms differ by weight rounding only)
+    assert rel(lit, ref) < 4e-3 and rel(sub, ref) < 6e-3, (rel(lit, ref), rel(sub, ref))
+    d = (sub.float().cpu() - ref).abs()
+    # borders and every parity: no pixel class is off (a wrong window origin shows as O(1) on a quarter of the pixels or on an edge)
+    for py in (0, 1):
+        for px in (0, 1):
+            assert float(d[:, :, py::2, px::2].max()) < 0.05 * float(ref.abs().max()), (py, px)
+    for sl in (d[:, :, 0], d[:, :, -1], d[:, :, :, 0], d[:, :, :, -1]):
+        assert float(sl.max()) < 0.05 * float(ref.abs().max())
+    assert torch.equal(sub, ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), upsample=True, subpix=True))
+
+
+def test_unet_decoder_uses_the_subpixel_upsampler_and_matches_the_literal_form():
+    """Model level: with the sub-pixel form forced on at any size (mrisr_debug_subpix(1)) the bf16 UNet agrees with the literal
+    up-sampled convs (mrisr_debug_subpix(0)) to weight-rounding level and with the oracle within the bf16 bound; the f32 engine and
+    the training graph never use it."""
+    import ctypes as C
+    import json
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg = ou.UNetConfig(block_out_channels=(64, 128, 256), attn_levels=(True, True, False), cross_attention_dim=64)
+    up = ou.init_unet_params(cfg, seed=301, perturb_norm=True)
+    g = torch.Generator().manual_seed(302)
+    x, ctx = torch.randn((2, 4, 16, 16), generator=g), torch.randn((2, 77, 64), generator=g)
+    t = torch.tensor([10, 900])
+    with torch.no_grad():
+        ref = ou.unet_forward(up, cfg, x, t, ctx)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16")
+    net.load_state_dict(up)
+    lib = L.lib()
+    try:
+        lib.mrisr_debug_subpix(C.c_int(0))
+        lit = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample.clone()
+        lib.mrisr_debug_subpix(C.c_int(1))
+        net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda())
+        lib.mrisr_prof_reset(); lib.mrisr_prof_enable(1)
+        sub = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample.clone()
+        torch.cuda.synchronize(); lib.mrisr_prof_enable(0)
+        buf = C.create_string_buffer(1 << 20)
+        n = lib.mrisr_prof_report(buf, len(buf))
+        cls = json.loads(buf.value[:n].decode())
+        lib.mrisr_prof_reset()
+    finally:
+        lib.mrisr_debug_subpix(C.c_int(-1))
+    assert cls.get("subpix_shuffle", {}).get("launches") == 2, sorted(cls)   # two upsamplers in a three-level decoder
+    assert rel(sub, ref) < 5e-2 and rel(lit, ref) < 5e-2 and rel(sub, lit) < 2e-2, (rel(sub, ref), rel(lit, ref), rel(sub, lit))

@@ -448,3 +448,49 @@ def test_ema_and_checkpoint_roundtrip(tiny, tmp_path):
     from mrisr.train import lora_keys_from_disk
     ema_sd = lora_keys_from_disk(load_file(str(tmp_path / "ema.safetensors")))
     assert rel(torch.cat([ema_sd[k].reshape(-1) for k, _, _ in tr.layout]), tr.ema) < 1e-7
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+def test_controlnet_residual_gradients_match_autograd(tiny, frozen):
+    """The training graph of the reference's ControlNet configuration (unet(..., down_block_additional_residuals=down_res,
+    mid_block_additional_residual=mid_res), res_srdiff.py:73-78): d(loss)/d(each of the 12 + 1 residuals) out of the UNet step -
+    the seeds of the ControlNet's own backward - against autograd on the oracle; with a FROZEN UNet (no adapters: inputs only) and
+    with LoRA trained alongside (the encoder's saved activations must not see the residuals: diffusers adds them out of place)."""
+    import mrisr
+    from oracle import unet as ou
+    cfg, up, lora = tiny
+    B, h = 2, 16
+    x, t, ctx, tgt = make_batch(cfg, B, h, 90, L=16)
+    g = torch.Generator().manual_seed(91)
+    chans, sizes = cfg.skip_channels(), [h, h, h, h // 2, h // 2, h // 2, h // 4, h // 4, h // 4, h // 8, h // 8, h // 8]
+    down = [(0.3 * torch.randn((B, c, s, s), generator=g)).requires_grad_(True) for c, s in zip(chans, sizes)]
+    mid = (0.3 * torch.randn((B, cfg.block_out_channels[-1], h // 8, h // 8), generator=g)).requires_grad_(True)
+    lp = {k: v.clone().requires_grad_(not frozen) for k, v in lora.items()}
+    params = dict(up) if frozen else {**up, **lp}
+    with torch.enable_grad():
+        pred = ou.unet_forward(params, cfg, x, t, ctx, down, mid, lora_scale=1.0)
+        loss_ref = torch.nn.functional.mse_loss(pred, tgt)
+        loss_ref.backward()
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32", lora_rank=0 if frozen else 4, lora_alpha=None if frozen else 4, lora_fused=True)
+    net.load_state_dict(params if frozen else {**up, **lora})
+    tr = mrisr.LoRATrainer(net)
+    assert (tr.num_trainable == 0) == frozen
+    dg = ([torch.zeros_like(d).cuda() for d in down], torch.zeros_like(mid).cuda())
+    loss, p = tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), return_pred=True,
+                                  down_block_additional_residuals=[d.detach().cuda() for d in down],
+                                  mid_block_additional_residual=mid.detach().cuda(), residual_grads=dg)
+    assert rel(p, pred) < 1e-3 and abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-3
+    for k, (a, d) in enumerate(zip(dg[0], down)):
+        assert rel(a, d.grad) < 1e-3, (k, rel(a, d.grad))
+    assert rel(dg[1], mid.grad) < 1e-3
+    if not frozen:
+        flat_ref = torch.cat([lp[k].grad.reshape(-1) for k, _, _ in tr.layout])
+        assert rel(tr.grad, flat_ref) < 1e-3, rel(tr.grad, flat_ref)
+    # and the residual state does not leak into the next plain step
+    if frozen:  # nothing is trainable and no input asks for a gradient: a clean error, not a silent no-op
+        with pytest.raises(mrisr.MrisrError, match="no trainable"):
+            tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda())
+    else:
+        l2, p2 = tr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), return_pred=True)
+        with torch.no_grad():
+            assert rel(p2, ou.unet_forward({k: v.detach() for k, v in params.items()}, cfg, x, t, ctx)) < 1e-3

@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 # like a GEMM library's logic file: the tuner's 3-launch timings are noisy enough to move the end-to-end figure by +-2 %
 # from run to run, a fixed table makes it repeatable.  Shapes that are not in the table are still tuned online (and
 # appended).  Override with MRISR_TUNE_CACHE=<path>, or MRISR_TUNE_CACHE= (empty) for pure online tuning.
-os.environ.setdefault("MRISR_TUNE_CACHE", os.path.join(ROOT, "profiles", "r02_tune_cache.tsv"))
+os.environ.setdefault("MRISR_TUNE_CACHE", os.path.join(ROOT, "profiles", "r03_tune_cache.tsv"))
 if not os.environ["MRISR_TUNE_CACHE"]:
     del os.environ["MRISR_TUNE_CACHE"]
 for p in (ROOT, os.path.join(ROOT, "mri-diffusion-superresolution_amd")):

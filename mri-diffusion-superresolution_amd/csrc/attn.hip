@@ -9,6 +9,7 @@
 // [b*h][dpad][token]) straight from the QKV GEMM epilogue; padding rows/columns are zero.
 #include "common.h"
 #include "prof.h"
+#include <type_traits>
 
 namespace mrisr {
 
@@ -144,86 +145,94 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
             commit((t + 1) & 1);
             if (t + 2 < ntiles) fetch();
         }
-        // ---- S^T - m for 64 keys x (QF*16) queries: 4 key blocks of 16 ----
-        f32x4 s[QF][4];
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
-#pragma unroll
-                for (int f = 0; f < QF; ++f) {
-                    const float nm = -m_run[f];
-                    const f32x4 c = kk == 0 ? f32x4{nm, nm, nm, nm} : s[f][tt];
-                    s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], c, 0, 0, 0);
+        // the tile's work as a function of its number of 16-key blocks: 4 (a full tile), or 1 when the LAST tile holds at most 16 keys
+        // - the 77-key cross-attention is 64 + 13 keys: its second tile then costs a quarter of the S MFMAs and exps and half the P V
+        // MFMAs instead of a whole masked tile (16 of the 32 attention launches of a step)
+        auto tile_work = [&](auto ttc) {
+            constexpr int TT = decltype(ttc)::value;
+            // ---- S^T - m for 64 keys x (QF*16) queries: 4 key blocks of 16 ----
+            f32x4 s[QF][TT];
+    #pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+    #pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + (tt * 16 + fr) * KP + (kk * 32 + fg * 8) * 2);
+    #pragma unroll
+                    for (int f = 0; f < QF; ++f) {
+                        const float nm = -m_run[f];
+                        const f32x4 c = kk == 0 ? f32x4{nm, nm, nm, nm} : s[f][tt];
+                        s[f][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][kk], c, 0, 0, 0);
+                    }
                 }
             }
-        }
-        const bool ragged = kt0 + KT > a.nk;  // only the last tile can hold masked keys (uniform branch)
-        uint4v pw[QF][2];  // P^T fragments as packed bf16 pairs (second MFMA operand)
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            if (ragged) {
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kt0 + tt * 16 + fg * 4 + r >= a.nk) s[f][tt][r] = -INFINITY;
+            const bool ragged = kt0 + KT > a.nk;  // only the last tile can hold masked keys (uniform branch)
+            uint4v pw[QF][2];  // P^T fragments as packed bf16 pairs (second MFMA operand)
+    #pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                if (ragged) {
+    #pragma unroll
+                    for (int tt = 0; tt < TT; ++tt)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kt0 + tt * 16 + fg * 4 + r >= a.nk) s[f][tt][r] = -INFINITY;
+                }
+                // lane owns q = fr; its 16 values are keys 16tt + 4fg + r, already relative to the running reference
+                float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
+    #pragma unroll
+                for (int tt = 1; tt < TT; ++tt) {
+                    mx = fmaxf(fmaxf(mx, s[f][tt][0]), s[f][tt][1]);
+                    mx = fmaxf(fmaxf(mx, s[f][tt][2]), s[f][tt][3]);
+                }
+                // move the reference only when it is needed: first tile (any sign), or some score of the tile is beyond 2^THR - tested
+                // on the lane-LOCAL maxima (no lane above THR <=> no score above THR), so the cross-lane exchange that makes the four
+                // lanes of a query agree on the new reference is paid only inside the rarely taken branch
+                if (t == 0 || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {
+                    mx = xor_max(mx);
+                    const float dlt = t == 0 ? mx : fmaxf(mx, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-dlt);  // (tile 0: the accumulators are zero, any factor is fine)
+                    m_run[f] += dlt;
+    #pragma unroll
+                    for (int tt = 0; tt < TT; ++tt)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) s[f][tt][r] -= dlt;
+                    if (t != 0) {
+                        l_run[f] *= alpha;
+    #pragma unroll
+                        for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
+                    }
+                }
+                float ps = 0.f;
+                if (TT < 4) pw[f][0] = pw[f][1] = uint4v{0u, 0u, 0u, 0u};  // key blocks past TT: p = 0
+    #pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+    #pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 p = {__builtin_amdgcn_exp2f(s[f][tt][r]), __builtin_amdgcn_exp2f(s[f][tt][r + 1])};
+                        if (!ONES) ps += p[0] + p[1];
+                        pw[f][tt >> 1][(tt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // one v_cvt_pk
+                    }
+                if (!ONES) l_run[f] += ps;
             }
-            // lane owns q = fr; its 16 values are keys 16tt + 4fg + r, already relative to the running reference
-            float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
-#pragma unroll
-            for (int tt = 1; tt < 4; ++tt) {
-                mx = fmaxf(fmaxf(mx, s[f][tt][0]), s[f][tt][1]);
-                mx = fmaxf(fmaxf(mx, s[f][tt][2]), s[f][tt][3]);
-            }
-            // move the reference only when it is needed: first tile (any sign), or some score of the tile is beyond 2^THR - tested
-            // on the lane-LOCAL maxima (no lane above THR <=> no score above THR), so the cross-lane exchange that makes the four
-            // lanes of a query agree on the new reference is paid only inside the rarely taken branch
-            if (t == 0 || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {
-                mx = xor_max(mx);
-                const float dlt = t == 0 ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-dlt);  // (tile 0: the accumulators are zero, any factor is fine)
-                m_run[f] += dlt;
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[f][tt][r] -= dlt;
-                if (t != 0) {
-                    l_run[f] *= alpha;
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) oacc[f][d] *= alpha;
+            // ---- O^T += V^T . P^T : two 32-key steps ----
+    #pragma unroll
+            for (int sub = 0; sub < (TT + 1) / 2; ++sub) {
+    #pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const char* vrow = v_lds + (d * 16 + fr) * VP + (sub * 32 + fg * 4) * 2;
+                    const short4v lo = *reinterpret_cast<const short4v*>(vrow);
+                    const short4v hi = *reinterpret_cast<const short4v*>(vrow + 32);
+                    typedef __attribute__((ext_vector_type(8))) short short8v;
+                    const short8v packed = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, packed);
+    #pragma unroll
+                    for (int f = 0; f < QF; ++f)
+                        oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[f][sub]), oacc[f][d], 0, 0, 0);
                 }
             }
-            float ps = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2 p = {__builtin_amdgcn_exp2f(s[f][tt][r]), __builtin_amdgcn_exp2f(s[f][tt][r + 1])};
-                    if (!ONES) ps += p[0] + p[1];
-                    pw[f][tt >> 1][(tt & 1) * 2 + (r >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // one v_cvt_pk
-                }
-            if (!ONES) l_run[f] += ps;
-        }
-        // ---- O^T += V^T . P^T : two 32-key steps ----
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                const char* vrow = v_lds + (d * 16 + fr) * VP + (sub * 32 + fg * 4) * 2;
-                const short4v lo = *reinterpret_cast<const short4v*>(vrow);
-                const short4v hi = *reinterpret_cast<const short4v*>(vrow + 32);
-                typedef __attribute__((ext_vector_type(8))) short short8v;
-                const short8v packed = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, packed);
-#pragma unroll
-                for (int f = 0; f < QF; ++f)
-                    oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[f][sub]), oacc[f][d], 0, 0, 0);
-            }
-        }
+        };
+        if (a.nk - kt0 <= 16) tile_work(std::integral_constant<int, 1>{});
+        else tile_work(std::integral_constant<int, 4>{});
     }
-
     // ---- normalise and store: lane holds O^T[d = 16db + 4fg + r][q = fr] ----
     const int b = bh / a.H, h = bh - b * a.H;
     bf16* ob = reinterpret_cast<bf16*>(a.out);

@@ -12,7 +12,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the tile / split-K table shipped with the library (read-only; see bench.py): GPU tests run the kernels the bench runs
-os.environ.setdefault("MRISR_TUNE_CACHE", os.path.join(ROOT, "profiles", "r02_tune_cache.tsv"))
+os.environ.setdefault("MRISR_TUNE_CACHE", os.path.join(ROOT, "profiles", "r03_tune_cache.tsv"))
 
 
 def pytest_configure(config):

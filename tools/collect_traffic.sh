@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
 # the shipped tile table (what bench.py uses), copied so that a missing signature would be appended to the copy only
-cp $R/profiles/r02_tune_cache.tsv $R/gpurun_out/tune_cache.tsv
+cp $R/profiles/r03_tune_cache.tsv $R/gpurun_out/tune_cache.tsv
 export MRISR_TUNE_CACHE=$R/gpurun_out/tune_cache.tsv
 # fill the autotune table first so that the profiled runs contain no tuning launches
 python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --ddim-steps 2 > $R/gpurun_out/traffic_warm.log 2>&1

@@ -19,7 +19,7 @@ from mrisr import _lib as L  # noqa: E402
 from mrisr import params as P  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 480.0
-table_path = os.path.join(ROOT, "profiles", "r02_tune_cache.tsv")
+table_path = os.path.join(ROOT, "profiles", "r03_tune_cache.tsv")
 os.environ["MRISR_TUNE_CACHE"] = table_path
 entries = []
 for line in open(table_path):

@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lora-merged", action="store_true", help="merge LoRA into W instead of the fused rank tail")
     ap.add_argument("--ddim-steps", type=int, default=N_DDIM, help="(profiling only) fewer denoising steps; the metric needs 50")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"),
                     help="per-kernel-class HBM bytes per launch from tools/collect_traffic.sh (PMC passes of this command)")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

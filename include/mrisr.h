@@ -244,6 +244,25 @@ int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, 
  * The UNet may be frozen (lora_rank 0: mrisr_train_bind(m, NULL, NULL, 0, stream)): the step then only computes these input gradients. */
 int mrisr_train_set_controlnet_residuals(mrisr_model* m, const mrisr_tensor* down, const mrisr_tensor* d_down, int n_down,
                                          const mrisr_tensor* mid, const mrisr_tensor* d_mid);
+/* ---- ControlNet with its own parameters trainable (NOT in the reference's code: it only runs a ControlNet for inference,
+ * src/adapters/res_srdiff.py:65-70; SURVEY.md 3.2 lists it as a training configuration).  The ControlNet handle's raw tensors live in
+ * ONE flat f32 vector the caller owns (offsets by mrisr_controlnet_train_tensor_info, key order = sorted state-dict names); one training
+ * step is  train_forward (recorded; writes the 12 + 1 residuals) -> mrisr_train_step of the UNet with those residuals
+ * (mrisr_train_set_controlnet_residuals: it writes d(loss)/d(residual)) -> train_backward (adds d(loss)/d(parameter) to the gradient
+ * vector) -> all-reduce, mrisr_optim_adamw on the flat vectors -> train_refresh (re-packs every weight in place).
+ * `differentiated` = 0 marks tensors whose gradient this build leaves at zero (norm affine parameters, the time-embedding MLP and its
+ * per-block projections, the condition embedding): keep them out of the optimiser or accept that they stay frozen. */
+int mrisr_controlnet_train_prepare(mrisr_model* m, void* stream);
+int64_t mrisr_controlnet_train_num_trainable(const mrisr_model* m);
+int mrisr_controlnet_train_num_tensors(const mrisr_model* m);
+int mrisr_controlnet_train_tensor_info(const mrisr_model* m, int i, const char** key, int64_t* offset, int64_t* numel, int* differentiated);
+int mrisr_controlnet_train_bind(mrisr_model* m, float* theta_dev, float* grad_dev, int init_from_model, void* stream);
+int mrisr_controlnet_train_refresh(mrisr_model* m, void* stream);
+int mrisr_controlnet_train_forward(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                                   const mrisr_tensor* cond, float conditioning_scale, mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out,
+                                   void* stream);
+int mrisr_controlnet_train_backward(mrisr_model* m, const mrisr_tensor* d_down, int n_down, const mrisr_tensor* d_mid, float conditioning_scale,
+                                    void* stream);
 int mrisr_optim_sumsq(const float* g_dev, int64_t n, float* out_dev, void* stream);
 /* ema = decay * ema + (1 - decay) * theta  (diffusers EMAModel.step on the flat trainable vector) */
 int mrisr_optim_ema(float* ema_dev, const float* theta_dev, int64_t n, float decay, void* stream);

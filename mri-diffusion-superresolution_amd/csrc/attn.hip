@@ -280,8 +280,11 @@ static int launch_dpad(const AttnArgs& a, hipStream_t st) {
     const bool ones = a.hd < DB * 16;
     // QF = 4 (a wave owns 64 queries): every K / V^T fragment read from LDS serves twice the MFMAs - the fp8 kernel, whose only
     // difference in the key loop is half the LDS bytes, runs 17 % faster than this one, so the loop is not purely VALU bound.
-    // Only where the registers allow it (head dims up to 64) and enough query blocks remain (MRISR_ATTN_QF4=0: off).
-    static const int qf4_env = [] { const char* e = getenv("MRISR_ATTN_QF4"); return e ? atoi(e) : 1; }();
+    // Only where the registers allow it (head dims up to 64) and enough query blocks remain.  OFF by default (MRISR_ATTN_QF4=1 turns it on):
+    // isolated it is 8 % faster (85.3 -> 78.3 us at N = 1,024), inside the step it is SLOWER - 112 vs 75 us per launch in the replayed graph,
+    // 61.7 vs 62.7 slices/s on one box, alternating runs (profiles/r03o_qf4_ab.log): at 236 VGPRs only two waves per SIMD are resident, and
+    // the kernel no longer hides the cold Q / K / V^T tiles the QKV GEMM has just written.
+    static const int qf4_env = [] { const char* e = getenv("MRISR_ATTN_QF4"); return e ? atoi(e) : 0; }();
     if constexpr (DPAD <= 64) {
         if (qf4_env && a.nq >= 512 && a.nk >= 256 && ones) {  // (77-key cross-attention: 25.0 -> 26.2 us with QF = 4; self-attention at N = 1024: 85.3 -> 78.3 us)
             hipLaunchKernelGGL((attn_fwd_kernel<DPAD, DB, 4, true>), dim3((a.nq + 255) / 256, BH), dim3(256), 0, st, a);

@@ -1159,6 +1159,53 @@ int launch_wgrad_accum_all(const float* tmp, float* gw, int Cout, int Cin, int t
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
+// ---- full-parameter training (ControlNet): the same two reductions with a source pitch, a source channel pitch (zero-padded layers)
+// and the GEGLU row interleave of `ff.net.0.proj` (packed row p of raw row r = g * half + j:  p = (j >> 4) * 32 + (j & 15) + 16 g)
+__device__ __forceinline__ int geglu_src(int r, int half) {
+    if (half <= 0) return r;
+    const int g = r >= half, j = g ? r - half : r;
+    return (j >> 4) * 32 + (j & 15) + (g ? 16 : 0);
+}
+// gw[(co * Cin + ci) * taps + tap] += tmp[src(co) * ld_tmp + tap * cin_src + ci]
+__global__ void wgrad_accum_gen_kernel(const float* __restrict__ tmp, int ld_tmp, int cin_src, float* gw, int Cout, int Cin, int taps, int half) {
+    const long long n = (long long)Cout * Cin * taps;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int tap = (int)(i % taps);
+        const long long cc = i / taps;
+        const int ci = (int)(cc % Cin);
+        const int co = (int)(cc / Cin);
+        gw[i] += tmp[(size_t)geglu_src(co, half) * ld_tmp + (size_t)tap * cin_src + ci];
+    }
+}
+int launch_wgrad_accum_gen(const float* tmp, int ld_tmp, int cin_src, float* gw, int Cout, int Cin, int taps, int geglu_half, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_accum_gen_kernel, dim3(bw_blocks((long long)Cout * Cin * taps)), dim3(256), 0, st, tmp, ld_tmp, cin_src, gw, Cout, Cin, taps, geglu_half);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// out[c] += sum_m dy[m * ld + col0 + src(c)]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_gen_kernel(const T* __restrict__ dy, int ld, int col0, float* out, int M, int C, int rows_per_block, int half) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int m_beg = blockIdx.y * rows_per_block, m_end = min(M, m_beg + rows_per_block);
+    float acc = 0.f;
+    if (c < C) {
+        const int sc = col0 + geglu_src(c, half);
+        for (int m = m_beg + sub; m < m_end; m += 4) acc += to_f32(dy[(size_t)m * ld + sc]);
+    }
+    red[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <typename T>
+int launch_colsum_gen(const void* dy, int ld, int col0, float* out, int M, int C, int geglu_half, hipStream_t st) {
+    const int rpb = 512;
+    hipLaunchKernelGGL(colsum_gen_kernel<T>, dim3((C + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, reinterpret_cast<const T*>(dy), ld, col0, out, M, C, rpb, geglu_half);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_colsum_gen<float>(const void*, int, int, float*, int, int, int, hipStream_t);
+template int launch_colsum_gen<bf16>(const void*, int, int, float*, int, int, int, hipStream_t);
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_accum_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, tmp, gw, n, taps, tap);
     MRISR_CHECK_HIP(hipGetLastError());

@@ -1,5 +1,6 @@
 // C ABI (include/mrisr.h): thin extern "C" layer over Model, plus the sampler (per-step hipGraph), the
 // T2I-Adapter runtime and the single-op entry points the parity tests call.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -1437,6 +1438,51 @@ int mrisr_train_set_intrablock_grads(mrisr_model* m, const mrisr_tensor* grads, 
     MRISR_REQUIRE(m && n >= 0 && n <= 4 && (n == 0 || grads), "feature-gradient outputs: 0..4 tensors");
     m->d_intra.assign(grads, grads + n);
     return 0;
+}
+// ---- full-parameter training of a ControlNet handle ----
+int mrisr_controlnet_train_prepare(mrisr_model* m, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->full_train_prepare((hipStream_t)stream);
+    API_END
+}
+int64_t mrisr_controlnet_train_num_trainable(const mrisr_model* m) { return m ? m->n_full : 0; }
+int mrisr_controlnet_train_num_tensors(const mrisr_model* m) { return m ? (int)m->full_trainables.size() : 0; }
+int mrisr_controlnet_train_tensor_info(const mrisr_model* m, int i, const char** key, int64_t* offset, int64_t* numel, int* differentiated) {
+    MRISR_REQUIRE(m && i >= 0 && i < (int)m->full_trainables.size() && key && offset && numel, "tensor index");
+    const auto& t = m->full_trainables[i];
+    *key = t.key.c_str();
+    *offset = t.offset;
+    *numel = t.numel;
+    if (differentiated) *differentiated = std::find(m->full_unsupported.begin(), m->full_unsupported.end(), t.key) == m->full_unsupported.end() ? 1 : 0;
+    return 0;
+}
+int mrisr_controlnet_train_bind(mrisr_model* m, float* theta_dev, float* grad_dev, int init_from_model, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->full_train_bind(theta_dev, grad_dev, init_from_model, (hipStream_t)stream);
+    API_END
+}
+int mrisr_controlnet_train_refresh(mrisr_model* m, void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->full_train_refresh((hipStream_t)stream);
+    API_END
+}
+int mrisr_controlnet_train_forward(mrisr_model* m, const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
+                                   const mrisr_tensor* cond, float conditioning_scale, mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out,
+                                   void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->controlnet_train_forward(sample, timestep, ehs, cond, conditioning_scale, down_out, n_down, mid_out, (hipStream_t)stream);
+    API_END
+}
+int mrisr_controlnet_train_backward(mrisr_model* m, const mrisr_tensor* d_down, int n_down, const mrisr_tensor* d_mid, float conditioning_scale,
+                                    void* stream) {
+    API_BEGIN
+    MRISR_REQUIRE(m, "null handle");
+    return m->controlnet_train_backward(d_down, n_down, d_mid, conditioning_scale, (hipStream_t)stream);
+    API_END
 }
 int mrisr_train_set_controlnet_residuals(mrisr_model* m, const mrisr_tensor* down, const mrisr_tensor* d_down, int n_down,
                                          const mrisr_tensor* mid, const mrisr_tensor* d_mid) {

@@ -246,6 +246,9 @@ template <typename T> int launch_relu_bwd(const void* dy, const void* h, void* o
 template <typename T> int launch_colsum(const void* dy, float* out, int M, int C, hipStream_t st);
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st);
 int launch_wgrad_accum_all(const float* tmp, float* gw, int Cout, int Cin, int taps, hipStream_t st);
+// full-parameter training: tmp rows with pitch ld_tmp, per-tap channel pitch cin_src (zero-padded layers), GEGLU row interleave (half > 0)
+int launch_wgrad_accum_gen(const float* tmp, int ld_tmp, int cin_src, float* gw, int Cout, int Cin, int taps, int geglu_half, hipStream_t st);
+template <typename T> int launch_colsum_gen(const void* dy, int ld, int col0, float* out, int M, int C, int geglu_half, hipStream_t st);
 template <typename T>
 int launch_im2col_all_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ks, int Mpad,
                         hipStream_t st);
@@ -331,6 +334,7 @@ template <typename T>
 int launch_nhwc_to_nchw(const void* src, void* dst, int dst_dtype, int B, int C, int H, int W, float scale,
                         hipStream_t st);
 template <typename T> int launch_add_inplace(void* x, const void* y, long long n, hipStream_t st);
+template <typename T> int launch_scale_inplace(void* p, float s, long long n, hipStream_t st);
 template <typename T> int launch_pixel_unshuffle_nchw(const void* src, int src_dtype, void* dst, int B, int C, int H,
                                                       int W, int r, hipStream_t st);
 // generic row copy/cast used by the weight packers:

@@ -788,6 +788,16 @@ int launch_pack_bias_geglu(const float* src, float* dst, int half, hipStream_t s
     return 0;
 }
 template <typename T>
+__global__ void scale_inplace_kernel(T* p, float s, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = from_f32<T>(to_f32(p[i]) * s);
+}
+template <typename T>
+int launch_scale_inplace(void* p, float s, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(scale_inplace_kernel<T>, dim3(nblocks(n)), dim3(256), 0, st, reinterpret_cast<T*>(p), s, n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <typename T>
 __global__ void fill_zero_kernel(T* p, long long n) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = from_f32<T>(0.f);
 }
@@ -926,6 +936,7 @@ int launch_quant_rows_fp8(const void* src_bf16, int rows, int cols, void* dst8, 
     template int launch_pack_conv3x3_padded<T>(const float*, void*, int, int, int, int, int, hipStream_t);         \
     template int launch_pack_conv_subpix<T>(const float*, void*, int, int, hipStream_t);                            \
     template int launch_subpix_shuffle<T>(const void*, void*, int, int, int, int, hipStream_t);                     \
+    template int launch_scale_inplace<T>(void*, float, long long, hipStream_t);                                     \
     template int launch_fill_zero<T>(void*, long long, hipStream_t);
 INST(float)
 INST(bf16)

@@ -106,6 +106,23 @@ struct Model {
     mrisr_tensor tr_mid{}, d_tr_mid{};
     bool has_tr_mid = false;
     std::string train_ws_key;
+    // ---- full-parameter training (ControlNet: every raw tensor is trainable; train.hip "full gradient" blocks) ----
+    std::map<std::string, long long> full_off;   // raw key -> offset in the caller's flat f32 vectors
+    std::vector<Trainable> full_trainables;      // every raw tensor, in key order (rows = shape[0], cols = the rest)
+    std::vector<std::string> full_unsupported;   // tensors whose gradient this build leaves at zero (reported to the host)
+    long long n_full = 0;
+    float* full_theta = nullptr;                 // caller-owned flat parameters / gradients (bound by full_train_bind)
+    float* full_grad = nullptr;
+    std::shared_ptr<void> full_tape;             // the recorded forward of full_train_forward (a Trainer<T>), consumed by full_train_backward
+    int full_train_prepare(hipStream_t st);
+    int full_train_bind(float* theta_dev, float* grad_dev, int init_from_model, hipStream_t st);
+    int full_train_refresh(hipStream_t st);      // copy theta back into the f32 masters and re-pack every weight
+    int repack(hipStream_t st);                  // finalize again INTO the existing packed buffers (same parameter set, new values)
+    bool repacking = false;
+    size_t repack_cursor = 0;
+    int controlnet_train_forward(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs, const mrisr_tensor* cond,
+                                 float scale, mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out, hipStream_t st);
+    int controlnet_train_backward(const mrisr_tensor* d_down, int n_down, const mrisr_tensor* d_mid, float scale, hipStream_t st);
     std::vector<LinW*> lora_linears();   // every LinW that carries adapters, fixed order
     int train_prepare(hipStream_t st);   // dgrad weight copies + trainable layout (after finalize)
     int train_bind(float* theta_dev, float* grad_dev, hipStream_t st);

@@ -50,6 +50,12 @@ const RawParam* Model::find(const std::string& k) const {
 }
 
 void* Model::new_packed(size_t bytes, bool zero) {
+    if (repacking && repack_cursor < packed.size()) {  // re-pack after an optimiser step: the same sequence of buffers, no allocation
+        DevBuf* b = packed[repack_cursor++].get();
+        if (b->bytes < (bytes ? bytes : 16)) { set_error("re-pack: packed buffer sequence changed"); return nullptr; }
+        if (zero && hipMemset(b->p, 0, bytes) != hipSuccess) return nullptr;
+        return b->p;
+    }
     packed.emplace_back(new DevBuf());
     if (packed.back()->reserve(bytes ? bytes : 16, zero)) return nullptr;
     return packed.back()->p;
@@ -283,7 +289,7 @@ template <typename T>
 static int finalize_t(Model& m, hipStream_t st) {
     Packer<T> pk(m, st);
     const mrisr_unet_cfg& c = m.cfg;
-    m.packed.clear();
+    if (!m.repacking) m.packed.clear();
     m.temb_mods.clear();
     m.tproj_total = 0;
     m.down.clear();
@@ -374,10 +380,19 @@ static int finalize_t(Model& m, hipStream_t st) {
     if (pk.err) return pk.err;
     MRISR_CHECK_HIP(hipStreamSynchronize(st));
     m.finalized = true;
-    m.ws_key = "";  // force workspace re-plan (cross-attention caches depend on weights)
+    if (!m.repacking) m.ws_key = "";  // force workspace re-plan (a re-pack keeps every geometry: only the caches below are stale)
     m.ctx_valid = false;
     m.cond_valid = false;
     return 0;
+}
+
+int Model::repack(hipStream_t st) {
+    MRISR_REQUIRE(finalized, "re-pack of a model that was never finalized");
+    repacking = true;
+    repack_cursor = 0;
+    const int rc = finalize(st);
+    repacking = false;
+    return rc;
 }
 
 int Model::finalize(hipStream_t st) {

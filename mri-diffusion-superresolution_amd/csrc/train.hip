@@ -225,6 +225,66 @@ struct Trainer : Runner<T> {
     // ---------------------------------------------------------------------------------------------
     // backward building blocks
     // ---------------------------------------------------------------------------------------------
+    // ---------------------------------------------------------------------------------------------
+    // full-parameter training (m.full_grad bound: ControlNet): weight / bias gradients of every conv and linear, accumulated into
+    // the caller's flat f32 vector at the raw tensor's offset (PyTorch layouts).  One pixel-contraction GEMM per layer,
+    //     dW[co][tap * cin + ci] = sum_m dY^T[co][m] . im2col^T[tap * cin + ci][m]
+    // (a linear / 1 x 1 conv is the ks = 1 case), then one scatter-add; db by column sums.
+    // ---------------------------------------------------------------------------------------------
+    bool full() const { return m.full_grad != nullptr; }
+    float* gptr(const std::string& key) const {
+        auto it = m.full_off.find(key);
+        return it == m.full_off.end() ? nullptr : m.full_grad + it->second;
+    }
+    // x: NHWC [xB][xH][xW][cin_src] (rows [M][cin_src] for a linear: xB = 1, xH = M, xW = 1); dY: rows [M][.] of pitch ldy, columns
+    // col0 .. col0 + cout_src; the raw tensor is [cout][cin][ks][ks] with cout <= cout_src, cin <= cin_src (zero-padded layers).
+    int wgrad(const void* x, int xB, int xH, int xW, int cin_src, const void* dY, int ldy, int col0, int Ho, int Wo, int cout_src, int ks,
+              int stride, float* gW, float* gB, int cout, int cin, int geglu_half = 0) {
+        const int M = xB * Ho * Wo, Mpad = (M + 63) / 64 * 64, taps = ks * ks;
+        const size_t mk = m.arena.mark();
+        T* dyT = static_cast<T*>(alloc((size_t)cout_src * Mpad * sizeof(T)));
+        T* xT = static_cast<T*>(alloc((size_t)taps * cin_src * Mpad * sizeof(T)));
+        float* tmp = static_cast<float*>(alloc((size_t)cout_src * taps * cin_src * sizeof(float)));
+        if (!dyT || !xT || !tmp) return 7;
+        if (!dry) {
+            if (Mpad != M) {
+                MRISR_CHECK_HIP(hipMemsetAsync(dyT, 0, (size_t)cout_src * Mpad * sizeof(T), st));
+                MRISR_CHECK_HIP(hipMemsetAsync(xT, 0, (size_t)taps * cin_src * Mpad * sizeof(T), st));
+            }
+            TRY(launch_transpose<T>(static_cast<const T*>(dY) + col0, dyT, M, cout_src, ldy, Mpad, 0, 0, 1, M, st));
+            if (gB) TRY(launch_colsum_gen<T>(dY, ldy, col0, gB, M, cout, geglu_half, st));
+            TRY(launch_im2col_all_T<T>(x, xT, xB, xH, xW, cin_src, Ho, Wo, stride, ks / 2, ks, Mpad, st));
+        }
+        GemmArgs g;
+        g.a0 = dyT; g.c0 = Mpad; g.lda0 = Mpad;
+        g.w = xT; g.M = cout_src; g.N = taps * cin_src; g.K = Mpad;
+        g.out_mode = OUT_F32; g.out = tmp; g.ldo = taps * cin_src;
+        TRY(R::run_gemm(g));
+        if (!dry && gW) TRY(launch_wgrad_accum_gen(tmp, taps * cin_src, cin_src, gW, cout, cin, taps, geglu_half, st));
+        m.arena.release(mk);
+        return 0;
+    }
+    int wgrad_conv(const Act& x, const Act& dy, const ConvW& cw, int stride) {
+        if (!full()) return 0;
+        const RawParam* w = m.find(cw.name + ".weight");
+        MRISR_REQUIRE(w && dy.C == cw.cout && x.C == cw.cin, "conv weight gradient: operands");
+        return wgrad(x.p, x.B, x.H, x.W, x.C, dy.p, dy.C, 0, dy.H, dy.W, dy.C, cw.ks, stride, gptr(cw.name + ".weight"), gptr(cw.name + ".bias"),
+                     (int)w->shape[0], (int)w->shape[1]);
+    }
+    // a (possibly fused) linear: one gradient GEMM per fused module on its column section of dY
+    int wgrad_linear(const LinW& lw, const void* x, int ldx, const void* dY, int ldy, int M) {
+        if (!full()) return 0;
+        MRISR_REQUIRE(ldx == lw.k && !lw.mod_names.empty(), "linear weight gradient: contiguous input rows of a named module");
+        const int nmod = (int)lw.mod_names.size(), secN = lw.n / nmod;
+        for (int j = 0; j < nmod; ++j) {
+            const std::string& name = lw.mod_names[j];
+            const bool geglu = name.size() > 13 && name.compare(name.size() - 13, 13, "ff.net.0.proj") == 0;
+            TRY(wgrad(x, 1, M, 1, lw.k, dY, ldy, j * secN, M, 1, secN, 1, 1, gptr(name + ".weight"), gptr(name + ".bias"), secN, lw.k,
+                      geglu ? secN / 2 : 0));
+        }
+        return 0;
+    }
+
     // dX (+)= conv3x3(dY, wd).  mode 1: the forward conv had stride 2 -> dY is zero-stuffed to twice its size
     int conv_dgrad(const Act& dy, const ConvW& cw, int mode, void* out, bool acc) {
         MRISR_REQUIRE(cw.wd && dy.C == cw.cout, "conv dgrad weights");
@@ -268,6 +328,7 @@ struct Trainer : Runner<T> {
         float* dz = nullptr;
         GemmArgs g;
         bool in_kernel = false, dx_done = false;
+        TRY(wgrad_linear(lw, x, ldx, dY, ldy, M));  // (full-parameter training only)
         if (need_dx) {
             MRISR_REQUIRE(lw.wT, "linear dgrad weights");
             g.a0 = dY; g.c0 = lw.n; g.lda0 = ldy;
@@ -512,8 +573,14 @@ struct Trainer : Runner<T> {
             Act dOa = o; dOa.p = dO;
             Act dhn = new_act(o.B, o.H, o.W, rr.cout), dh = new_act(o.B, o.H, o.W, rr.cout), dxn = new_act(o.B, o.H, o.W, rr.cin);
             if (!dhn.p || !dh.p || !dxn.p) return 7;
+            TRY(wgrad_conv(hn, dOa, rr.c2, 1));
             TRY(conv_dgrad(dOa, rr.c2, 0, dhn.p, false));
             TRY(gn_bwd(h, nullptr, rr.n2, true, m.cfg.norm_eps, p2, ns2, dhn.p, dh.p, false, nullptr, false));
+            TRY(wgrad_conv(xn, dh, rr.c1, 1));
+            if (full() && rr.has_sc) {
+                MRISR_REQUIRE(!has_x1, "full-parameter training: single-source shortcut");
+                TRY(wgrad_linear(rr.sc, x.p, x.C, dO, rr.cout, (int)x.rows()));
+            }
             TRY(conv_dgrad(dh, rr.c1, 0, dxn.p, false));
             TRY(gn_bwd(x, has_x1 ? &x1v : nullptr, rr.n1, true, m.cfg.norm_eps, p1, ns1, dxn.p, s0.g, s0.written,
                        s1 ? s1->g : nullptr, s1 ? s1->written : false));
@@ -591,7 +658,7 @@ struct Trainer : Runner<T> {
         TRY(R::linear(t3, M, C, xw.proj_out, ACT_NONE, x.p, C, nullptr, o.p, C, &z_po));
         *out = o;
         const bool x_live = is_live(x);
-        if (!x_live && !has_lora(xw)) return 0;
+        if (!x_live && !has_lora(xw) && !full()) return 0;
         live.insert(o.p);
         const XfW* xp = &xw;
         const HeadBuf hbv = hb;
@@ -606,8 +673,9 @@ struct Trainer : Runner<T> {
             auto brows = [&](size_t r, int c) { return static_cast<T*>(alloc(r * c * sizeof(T))); };
             T *dt = brows(M, C), *dn = brows(M, C), *dao = brows(M, C), *dq = brows(M, C);
             T *dff = brows(M, 4 * C), *dpre = brows(M, 8 * C), *dqkv = brows(M, 3 * C);
-            T* dkv = w.kv2.R ? brows(Bc, 2 * C) : nullptr;
-            if (!dt || !dn || !dao || !dq || !dff || !dpre || !dqkv || (w.kv2.R && !dkv)) return 7;
+            const bool want_kv = w.kv2.R || full();
+            T* dkv = want_kv ? brows(Bc, 2 * C) : nullptr;
+            if (!dt || !dn || !dao || !dq || !dff || !dpre || !dqkv || (want_kv && !dkv)) return 7;
             // o = proj_out(t3) + x
             TRY(linear_bwd(w.proj_out, t3, C, z_po, dO, C, M, dt, false, true));
             // t3 = t2 + ff2(geglu(ff1(LN3(t2))))
@@ -724,6 +792,111 @@ struct Trainer : Runner<T> {
             sx.written = true;
             return 0;
         });
+        return 0;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // ControlNet with every parameter trainable (full-parameter mode).  Forward = Runner::controlnet_forward's sequence, recorded;
+    // the backward is seeded with d(loss)/d(residual k) - what the UNet's step exported (mrisr_train_set_controlnet_residuals).
+    // ---------------------------------------------------------------------------------------------
+    std::vector<Act> cn_skips;
+    Act cn_x;  // mid-block output
+    int cn_forward(const mrisr_tensor& sample, const long long* t_dev, int t_scalar, const mrisr_tensor& ehs, const mrisr_tensor& cond, float scale,
+                   mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out) {
+        m.arena.reset();
+        const int B = (int)sample.shape[0];
+        TRY(set_context_t(ehs));
+        TRY(R::set_cond(cond));  // (the condition embedding's own gradients: not differentiated yet - reported in full_unsupported)
+        TRY(R::time_embed(t_dev, t_scalar, B));
+        Act s, x;
+        TRY(R::import_act(sample, &s, false));
+        Act ce;
+        ce.p = m.cond_emb; ce.B = B; ce.H = s.H; ce.W = s.W; ce.C = m.cfg.block_out_channels[0];
+        TRY(R::direct(s, m.conv_in, 1, ACT_NONE, &ce, &x));
+        live.insert(x.p);
+        {   // conv_in's own weights (4 input channels: the generic pixel-contraction path)
+            const Act sv = s, xv = x;
+            tape.push_back([=]() -> int {
+                auto it = slots.find(xv.p);
+                MRISR_REQUIRE(it != slots.end() && it->second.written, "conv_in output has no gradient");
+                Act dy = xv; dy.p = it->second.g;
+                return wgrad_conv(sv, dy, m.conv_in, 1);
+            });
+        }
+        cn_skips.clear();
+        cn_skips.push_back(x);
+        for (int i = 0; i < m.cfg.num_levels; ++i) {
+            Level& lv = m.down[i];
+            const bool has_attn = !lv.xf.empty();
+            for (size_t j = 0; j < lv.res.size(); ++j) {
+                Act y;
+                TRY(resnet_t(lv.res[j], x, nullptr, &y));
+                x = y;
+                if (has_attn) {
+                    TRY(transformer_t(lv.xf[j], x, &y));
+                    x = y;
+                }
+                cn_skips.push_back(x);
+            }
+            if (lv.has_down) {
+                Act y;
+                TRY(R::conv3(x, nullptr, lv.down, 2, 0, nullptr, 0, 1, nullptr, ACT_NONE, &y));
+                live.insert(y.p);
+                const ConvW* cw = &lv.down;
+                const Act xin = x;
+                tape.push_back([=]() -> int {
+                    auto it = slots.find(y.p);
+                    MRISR_REQUIRE(it != slots.end() && it->second.written, "downsample output has no gradient");
+                    Slot& sx = slot(xin);
+                    Act dy = y; dy.p = it->second.g;
+                    TRY(wgrad_conv(xin, dy, *cw, 2));
+                    TRY(conv_dgrad(dy, *cw, 1, sx.g, sx.written));
+                    sx.written = true;
+                    return 0;
+                });
+                x = y;
+                cn_skips.push_back(x);
+            }
+        }
+        {
+            Act y;
+            TRY(resnet_t(m.mid_r0, x, nullptr, &y));
+            x = y;
+            TRY(transformer_t(m.mid_xf, x, &y));
+            x = y;
+            TRY(resnet_t(m.mid_r1, x, nullptr, &y));
+            x = y;
+        }
+        cn_x = x;
+        MRISR_REQUIRE(n_down == (int)cn_skips.size(), "ControlNet output count");
+        for (int k = 0; k <= n_down; ++k) {  // the zero convs (k == n_down: the mid block's)
+            const Act& a = k < n_down ? cn_skips[k] : cn_x;
+            const LinW& zw = k < n_down ? m.cn_down[k] : m.cn_mid;
+            Act o = new_act(a.B, a.H, a.W, a.C);
+            if (!o.p) return 7;
+            TRY(R::linear(a.p, (int)a.rows(), a.C, zw, ACT_NONE, nullptr, 0, nullptr, o.p, o.C));
+            mrisr_tensor* dst = k < n_down ? &down_out[k] : mid_out;
+            if (dst && dst->data) TRY(R::export_act(o, *dst, scale));
+        }
+        return 0;
+    }
+    int cn_backward(const mrisr_tensor* d_down, int n_down, const mrisr_tensor* d_mid, float scale) {
+        MRISR_REQUIRE(n_down == (int)cn_skips.size() && d_mid, "one gradient per ControlNet residual");
+        for (int k = n_down; k >= 0; --k) {
+            const Act& a = k < n_down ? cn_skips[k] : cn_x;
+            const LinW& zw = k < n_down ? m.cn_down[k] : m.cn_mid;
+            const mrisr_tensor& src = k < n_down ? d_down[k] : *d_mid;
+            MRISR_REQUIRE(src.ndim == 4 && src.shape[0] == a.B && src.shape[1] == a.C && src.shape[2] == a.H && src.shape[3] == a.W, "residual gradient shape");
+            Slot& sa = slot(a);  // (allocates the gradient buffer on first use: BEFORE the mark, it must outlive this scope)
+            const size_t mk = m.arena.mark();
+            Act dy;
+            TRY(R::import_act(src, &dy, true));
+            if (scale != 1.0f && !dry) TRY(launch_scale_inplace<T>(dy.p, scale, (long long)dy.numel(), st));
+            TRY(linear_bwd(zw, a.p, a.C, nullptr, dy.p, a.C, (int)a.rows(), sa.g, sa.written, true));
+            sa.written = true;
+            m.arena.release(mk);
+        }
+        for (size_t i = tape.size(); i-- > 0;) TRY(tape[i]());
         return 0;
     }
 
@@ -882,6 +1055,148 @@ struct Trainer : Runner<T> {
         return 0;
     }
 };
+
+// ================================================================================================
+// full-parameter training of a ControlNet handle
+// ================================================================================================
+template <typename T>
+static int full_train_prepare_t(Model& m, hipStream_t st) {
+    int err = 0;
+    auto conv_dgrad = [&](ConvW& c) {
+        if (!c.w || c.ks != 3 || c.wd) return;
+        const RawParam* w = m.find(c.name + ".weight");
+        if (!w) { err = 3; set_error("missing parameter: " + c.name + ".weight"); return; }
+        c.wd = m.new_packed((size_t)w->numel() * sizeof(T), false);
+        if (!c.wd) { err = 4; return; }
+        long long blocks = (w->numel() + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(pack_conv_dgrad_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(w->data->p),
+                           static_cast<T*>(c.wd), c.cout, c.cin);
+    };
+    auto lin_t = [&](LinW& l) {
+        if (!l.w) return;
+        if (!l.wT) l.wT = m.new_packed((size_t)l.n * l.k * sizeof(T), false);
+        if (!l.wT) { err = 4; return; }
+        if (launch_transpose<T>(l.w, l.wT, l.n, l.k, l.k, l.n, 0, 0, 1, l.n, st)) err = 5;
+    };
+    for (auto& lv : m.down) {
+        for (auto& r : lv.res) { conv_dgrad(r.c1); conv_dgrad(r.c2); if (r.has_sc) lin_t(r.sc); }
+        if (lv.has_down) conv_dgrad(lv.down);
+        for (auto& x : lv.xf) for (LinW* l : {&x.proj_in, &x.qkv, &x.out1, &x.q2, &x.out2, &x.ff1, &x.ff2, &x.proj_out}) lin_t(*l);
+    }
+    for (ResW* r : {&m.mid_r0, &m.mid_r1}) { conv_dgrad(r->c1); conv_dgrad(r->c2); if (r->has_sc) lin_t(r->sc); }
+    for (LinW* l : {&m.mid_xf.proj_in, &m.mid_xf.qkv, &m.mid_xf.out1, &m.mid_xf.q2, &m.mid_xf.out2, &m.mid_xf.ff1, &m.mid_xf.ff2, &m.mid_xf.proj_out}) lin_t(*l);
+    for (auto& l : m.cn_down) lin_t(l);
+    lin_t(m.cn_mid);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return err;
+}
+
+int Model::full_train_prepare(hipStream_t st) {
+    MRISR_REQUIRE(finalized && is_controlnet, "full-parameter training is implemented for a finalized ControlNet handle");
+    MRISR_REQUIRE(cfg.lora_rank == 0, "full-parameter training: no adapters on the ControlNet");
+    full_off.clear();
+    full_trainables.clear();
+    full_unsupported.clear();
+    long long off = 0;
+    for (auto& kv : raw) {  // key order: the layout is a property of the parameter names alone
+        const RawParam& r = kv.second;
+        const long long rows = r.shape.empty() ? 1 : r.shape[0];
+        full_off[kv.first] = off;
+        full_trainables.push_back({kv.first, off, r.numel(), (int)rows, (int)(r.numel() / (rows ? rows : 1))});
+        off += r.numel();
+        // what this build differentiates: every conv / linear weight and bias of the encoder, mid block and zero convs.  Still frozen
+        // (gradient left at zero): norm affine parameters, the time-embedding MLP and its per-block projections, the condition embedding
+        const std::string& k = kv.first;
+        auto has = [&](const char* s) { return k.find(s) != std::string::npos; };
+        if (has("norm") || has("time_emb") || has("controlnet_cond_embedding")) full_unsupported.push_back(k);
+    }
+    n_full = off;
+    return cfg.compute_dtype == MRISR_F32 ? full_train_prepare_t<float>(*this, st) : full_train_prepare_t<bf16>(*this, st);
+}
+
+int Model::full_train_bind(float* theta_dev, float* grad_dev, int init_from_model, hipStream_t st) {
+    if (full_off.empty()) TRY(full_train_prepare(st));
+    MRISR_REQUIRE(theta_dev && grad_dev, "theta / grad device buffers");
+    full_theta = theta_dev;
+    full_grad = grad_dev;
+    if (init_from_model)
+        for (auto& t : full_trainables)
+            MRISR_CHECK_HIP(hipMemcpyAsync(theta_dev + t.offset, raw.at(t.key).data->p, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// after an optimiser step: theta -> the f32 masters, every packed weight (forward and dgrad copies) rebuilt in place
+int Model::full_train_refresh(hipStream_t st) {
+    MRISR_REQUIRE(full_theta, "bind the trainable vector first");
+    for (auto& t : full_trainables)
+        MRISR_CHECK_HIP(hipMemcpyAsync(raw.at(t.key).data->p, full_theta + t.offset, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    TRY(repack(st));
+    cond_valid = false;
+    ctx_valid = false;
+    return cfg.compute_dtype == MRISR_F32 ? full_train_prepare_t<float>(*this, st) : full_train_prepare_t<bf16>(*this, st);
+}
+
+template <typename T>
+static int cn_forward_t(Model& m, const mrisr_tensor& sample, const long long* t, int t_scalar, const mrisr_tensor& ehs, const mrisr_tensor& cond,
+                        float scale, mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out, hipStream_t st) {
+    m.full_tape.reset();
+    if (m.train_ws_key != m.ws_key) {  // dry pass of forward + backward sizes the arena exactly
+        ++m.ws_gen;
+        m.arena.dry = true;
+        m.arena.reset();
+        m.arena.peak = 0;
+        int rc;
+        {
+            Trainer<T> tr(m, st, true);
+            rc = tr.cn_forward(sample, t, t_scalar, ehs, cond, scale, down_out, n_down, mid_out);
+            if (!rc) {
+                std::vector<mrisr_tensor> dd(down_out, down_out + n_down);
+                rc = tr.cn_backward(dd.data(), n_down, mid_out, scale);
+            }
+        }
+        m.arena.dry = false;
+        if (rc) return rc;
+        MRISR_CHECK_HIP(hipStreamSynchronize(st));
+        TRY(m.arena.buf.reserve(m.arena.peak + 4096, false));
+        m.arena.reset();
+        m.train_ws_key = m.ws_key;
+    }
+    auto tr = std::make_shared<Trainer<T>>(m, st, false);
+    TRY(tr->cn_forward(sample, t, t_scalar, ehs, cond, scale, down_out, n_down, mid_out));
+    m.full_tape = tr;
+    return 0;
+}
+
+int Model::controlnet_train_forward(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs, const mrisr_tensor* cond,
+                                    float scale, mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out, hipStream_t st) {
+    MRISR_REQUIRE(is_controlnet && full_grad, "bind the ControlNet's trainable vector first (mrisr_controlnet_train_bind)");
+    MRISR_REQUIRE(sample && sample->ndim == 4 && timestep && timestep->dtype == MRISR_I64 && ehs && ehs->ndim == 3 && cond && down_out && mid_out,
+                  "ControlNet training forward: sample, timestep, encoder_hidden_states, controlnet_cond, outputs");
+    const int B = (int)sample->shape[0], h = (int)sample->shape[2], w = (int)sample->shape[3];
+    const int t_scalar = timestep->ndim == 0 || timestep->shape[0] == 1;
+    MRISR_REQUIRE(t_scalar || timestep->shape[0] == B, "timestep length");
+    keep = true;
+    int rc = ensure_workspace(B, h, w, (int)ehs->shape[1], st);
+    if (!rc) {
+        const long long* t = static_cast<const long long*>(timestep->data);
+        rc = cfg.compute_dtype == MRISR_F32 ? cn_forward_t<float>(*this, *sample, t, t_scalar, *ehs, *cond, scale, down_out, n_down, mid_out, st)
+                                            : cn_forward_t<bf16>(*this, *sample, t, t_scalar, *ehs, *cond, scale, down_out, n_down, mid_out, st);
+    }
+    keep = false;
+    return rc;
+}
+
+int Model::controlnet_train_backward(const mrisr_tensor* d_down, int n_down, const mrisr_tensor* d_mid, float scale, hipStream_t st) {
+    MRISR_REQUIRE(full_tape, "run mrisr_controlnet_train_forward first (its recorded forward is consumed by ONE backward)");
+    keep = true;
+    int rc;
+    if (cfg.compute_dtype == MRISR_F32) rc = static_cast<Trainer<float>*>(full_tape.get())->cn_backward(d_down, n_down, d_mid, scale);
+    else rc = static_cast<Trainer<bf16>*>(full_tape.get())->cn_backward(d_down, n_down, d_mid, scale);
+    keep = false;
+    full_tape.reset();
+    return rc;
+}
 
 template <typename T>
 static int train_step_t(Model& m, const mrisr_tensor& sample, const long long* t, int t_scalar, const mrisr_tensor& ehs,

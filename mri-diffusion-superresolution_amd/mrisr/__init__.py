@@ -10,7 +10,7 @@ from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
 from .train import LoRATrainer, cosine_lr  # noqa: F401
 from .vae import AutoencoderKL, VAEConfig, vae_param_shapes  # noqa: F401
 from .metrics import MRIEvaluator  # noqa: F401
-from .train import AdapterTrainer, joint_step, joint_step_overlapped  # noqa: F401
+from .train import AdapterTrainer, ControlNetTrainer, joint_step, joint_step_overlapped  # noqa: F401
 from .dist import BucketedReducer  # noqa: F401
 from .datasets import (FastMRILazyDataset, SliceDataset, gaussian_blur, get_data_dicts_artificial,  # noqa: F401
                        pad_or_center_crop, resize_slices, simulate_low_field)

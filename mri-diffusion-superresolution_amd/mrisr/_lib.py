@@ -67,7 +67,7 @@ EXPORTS = [
     "mrisr_resize_scratch_bytes", "mrisr_resize_slices", "mrisr_gaussian_blur_slices", "mrisr_low_field_scratch_bytes",
     "mrisr_simulate_low_field",
     "mrisr_train_prepare", "mrisr_train_num_trainable", "mrisr_train_num_tensors", "mrisr_train_tensor_info",
-    "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_train_set_intrablock_grads", "mrisr_train_set_controlnet_residuals", "mrisr_optim_sumsq", "mrisr_optim_adamw", "mrisr_optim_ema",
+    "mrisr_train_bind", "mrisr_train_refresh", "mrisr_train_step", "mrisr_train_set_intrablock_grads", "mrisr_train_set_controlnet_residuals", "mrisr_controlnet_train_prepare", "mrisr_controlnet_train_num_trainable", "mrisr_controlnet_train_num_tensors", "mrisr_controlnet_train_tensor_info", "mrisr_controlnet_train_bind", "mrisr_controlnet_train_refresh", "mrisr_controlnet_train_forward", "mrisr_controlnet_train_backward", "mrisr_optim_sumsq", "mrisr_optim_adamw", "mrisr_optim_ema",
     "mrisr_prof_enable", "mrisr_prof_reset", "mrisr_prof_report",
     "mrisr_op_conv3x3", "mrisr_op_linear", "mrisr_op_ln_linear", "mrisr_op_linear_fp8", "mrisr_op_mlp", "mrisr_op_groupnorm", "mrisr_op_layernorm", "mrisr_op_attention",
     "mrisr_op_attention_bwd",

@@ -280,6 +280,105 @@ class LoRATrainer(_FlatAdamW):
         return loss
 
 
+class ControlNetTrainer(_FlatAdamW):
+    """A ``ControlNetModel`` with its own parameters trainable (the reference itself only runs a ControlNet for
+    inference, res_srdiff.py:65-70).  All raw tensors live in one flat f32 vector (``self.theta``; ``self.layout`` maps state-dict keys
+    to offsets); ``self.frozen`` lists the tensors this build does not differentiate (norm affine, time embedding, condition embedding):
+    their gradient stays zero and ``optimizer_step`` masks them out of the weight decay as well.
+
+        down, mid = cn.forward(x_t, t, ehs, cond)                       # recorded forward
+        dg = ([torch.zeros_like(d) for d in down], torch.zeros_like(mid))
+        loss = unet_trainer.forward_backward(x_t, t, ehs, target, down_block_additional_residuals=down,
+                                             mid_block_additional_residual=mid, residual_grads=dg)
+        cn.backward(*dg); cn.optimizer_step()
+    """
+
+    def __init__(self, controlnet, lr: float = 1e-5, betas: Tuple[float, float] = (0.9, 0.999), weight_decay: float = 1e-2,
+                 eps: float = 1e-8, max_grad_norm: float = 1.0, process_group=None, conditioning_scale: float = 1.0):
+        if not getattr(controlnet, "_finalized", False):
+            raise L.MrisrError("load_state_dict() first")
+        self.controlnet, self.scale = controlnet, float(conditioning_scale)
+        lib = L.lib()
+        lib.mrisr_controlnet_train_num_trainable.restype = C.c_int64
+        lib.mrisr_controlnet_train_num_trainable.argtypes = [C.c_void_p]
+        lib.mrisr_controlnet_train_num_tensors.argtypes = [C.c_void_p]
+        L.check(lib.mrisr_controlnet_train_prepare(controlnet._h, L.stream_ptr()))
+        n = int(lib.mrisr_controlnet_train_num_trainable(controlnet._h))
+        self._init_flat(n, controlnet.device, lr, betas, weight_decay, eps, max_grad_norm, process_group)
+        shapes = {k: tuple(v.shape) for k, v in controlnet._params.items()}
+        self.layout: List[Tuple[str, int, Tuple[int, ...]]] = []
+        self.frozen: List[str] = []
+        for i in range(int(lib.mrisr_controlnet_train_num_tensors(controlnet._h))):
+            key, off, num, ok = C.c_char_p(), C.c_int64(), C.c_int64(), C.c_int()
+            L.check(lib.mrisr_controlnet_train_tensor_info(controlnet._h, i, C.byref(key), C.byref(off), C.byref(num), C.byref(ok)))
+            k = key.value.decode()
+            self.layout.append((k, int(off.value), shapes.get(k, (int(num.value),))))
+            if not ok.value:
+                self.frozen.append(k)
+        L.check(lib.mrisr_controlnet_train_bind(controlnet._h, C.c_void_p(self.theta.data_ptr()), C.c_void_p(self.grad.data_ptr()), 1, L.stream_ptr()))
+
+    def _views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        for k, o, shp in self.layout:
+            n = 1
+            for d in shp:
+                n *= d
+            out[k] = flat[o:o + n].view(*shp) if shp else flat[o:o + 1].view(())
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.clone() for k, v in self._views(self.theta).items()}
+
+    def gradients(self) -> Dict[str, torch.Tensor]:
+        return self._views(self.grad)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        views = self._views(self.theta)
+        for k, v in sd.items():
+            if k in views:
+                views[k].copy_(v.to(self.theta.device, torch.float32))
+        L.check(L.lib().mrisr_controlnet_train_refresh(self.controlnet._h, L.stream_ptr()))
+
+    def forward(self, sample: torch.Tensor, timesteps, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor):
+        """``controlnet(sample, t, encoder_hidden_states=..., controlnet_cond=..., return_dict=False)`` with the forward recorded for
+        ONE following ``backward``.  Returns (list of 12 residuals, mid residual), f32 NCHW."""
+        cn = self.controlnet
+        x = sample.to(cn.device).contiguous()
+        B, _, h, w = x.shape
+        t = cn._timestep(timesteps, B)
+        ehs = encoder_hidden_states.to(cn.device).contiguous()
+        cond = controlnet_cond.to(cn.device).contiguous()
+        shapes = cn._skip_shapes(B, h, w)
+        outs = [torch.empty(s, dtype=torch.float32, device=cn.device) for s in shapes]
+        o_arr = L.tensor_array([L.as_tensor(o) for o in outs[:-1]])
+        t_x, t_t, t_e, t_c, t_m = L.as_tensor(x), L.as_tensor(t), L.as_tensor(ehs), L.as_tensor(cond), L.as_tensor(outs[-1])
+        L.check(L.lib().mrisr_controlnet_train_forward(cn._h, C.byref(t_x), C.byref(t_t), C.byref(t_e), C.byref(t_c), C.c_float(self.scale),
+                                                       o_arr, len(outs) - 1, C.byref(t_m), L.stream_ptr()))
+        return outs[:-1], outs[-1]
+
+    def backward(self, d_down: Sequence[torch.Tensor], d_mid: torch.Tensor):
+        """Adds d(loss)/d(parameter) to ``self.grad`` given d(loss)/d(residual) (what ``LoRATrainer.forward_backward(...,
+        residual_grads=...)`` wrote)."""
+        cn = self.controlnet
+        g = [d.to(cn.device).contiguous() for d in d_down]
+        gm = d_mid.to(cn.device).contiguous()
+        arr = L.tensor_array([L.as_tensor(d) for d in g])
+        t_m = L.as_tensor(gm)
+        L.check(L.lib().mrisr_controlnet_train_backward(cn._h, arr, len(g), C.byref(t_m), C.c_float(self.scale), L.stream_ptr()))
+
+    def optimizer_step(self, world: int = 1, lr: Optional[float] = None, sumsq: Optional[torch.Tensor] = None):
+        """clip + AdamW on the flat vectors, then the new values are re-packed into the handle (forward and dgrad weight copies)."""
+        if self.frozen:  # no gradient -> no update, weight decay included: restore those slices after the step
+            views = self._views(self.theta)
+            keep = {k: views[k].clone() for k in self.frozen}
+        self._adamw(world, lr, sumsq)
+        if self.frozen:
+            views = self._views(self.theta)
+            for k, v in keep.items():
+                views[k].copy_(v)
+        L.check(L.lib().mrisr_controlnet_train_refresh(self.controlnet._h, L.stream_ptr()))
+
+
 class AdapterTrainer(_FlatAdamW):
     """The reference's T2I-Adapter (``Adapter_XL``, src/adapters/modules.py:114-157) as a trainable module: every conv
     weight / bias lives in one flat f32 vector (state-dict keys and shapes via ``layout``), ``forward`` is the adapter

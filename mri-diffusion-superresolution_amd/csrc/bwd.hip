@@ -1206,6 +1206,193 @@ int launch_colsum_gen(const void* dy, int ld, int col0, float* out, int M, int C
 }
 template int launch_colsum_gen<float>(const void*, int, int, float*, int, int, int, hipStream_t);
 template int launch_colsum_gen<bf16>(const void*, int, int, float*, int, int, int, hipStream_t);
+// ---- affine parameters of the norms, time-embedding path (full-parameter training) ------------------------------------------------
+// GroupNorm(+SiLU): g_gamma[c] += sum_{b,hw} dpre xhat, g_beta[c] += sum dpre, dpre = dy (* silu'(gamma xhat + beta)); mean / rstd from the
+// forward's partial sums.  grid (B, ceil(C / 64)); 64 channels x 4 row lanes per block; one atomic per channel and block.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_affine_grad_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ fwd_partial, int nsplit,
+                                                             int groups, int HW, int C, float eps, int silu, float* g_gamma, float* g_beta) {
+    __shared__ float red[2][4][64];
+    __shared__ float mean_s[64], rstd_s[64];
+    const int b = blockIdx.x, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int Cg = C / groups, c = c0 + lane;
+    const int g0 = c0 / Cg, g1 = min(groups - 1, (c0 + 63) / Cg);
+    if ((int)threadIdx.x <= g1 - g0) {
+        const int gq = g0 + threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < nsplit; ++q) {
+            const float* p = fwd_partial + (((size_t)b * nsplit + q) * groups + gq) * 2;
+            s1 += (double)p[0];
+            s2 += (double)p[1];
+        }
+        const double n = (double)HW * Cg, mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[threadIdx.x] = (float)mean;
+        rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    float ag = 0.f, ab = 0.f;
+    if (c < C) {
+        const int gl = c / Cg - g0;
+        const float mu = mean_s[gl], rs = rstd_s[gl], ga = gamma[c], be = beta[c];
+        for (int r = sub; r < HW; r += 4) {
+            const size_t o = ((size_t)b * HW + r) * C + c;
+            const float xh = (to_f32(x[o]) - mu) * rs;
+            float d = to_f32(dy[o]);
+            if (silu) d *= silu_grad(xh * ga + be);
+            ag += d * xh;
+            ab += d;
+        }
+    }
+    red[0][sub][lane] = ag;
+    red[1][sub][lane] = ab;
+    __syncthreads();
+    if (sub == 0 && c < C) {
+        atomicAdd(g_gamma + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+        atomicAdd(g_beta + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+    }
+}
+template <typename T>
+int launch_gn_affine_grad(const void* x, const void* dy, const float* gamma, const float* beta, const float* fwd_partial, int nsplit, int groups,
+                          int B, int HW, int C, float eps, int silu, float* g_gamma, float* g_beta, hipStream_t st) {
+    MRISR_REQUIRE(C % groups == 0 && C / groups <= 64 * 64, "GroupNorm affine gradient: group size");
+    hipLaunchKernelGGL(gn_affine_grad_kernel<T>, dim3(B, (C + 63) / 64), dim3(256), 0, st, reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy),
+                       gamma, beta, fwd_partial, nsplit, groups, HW, C, eps, silu, g_gamma, g_beta);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// LayerNorm: g_gamma[c] += sum_rows dy xhat, g_beta[c] += sum_rows dy.  A wave owns a run of rows (statistics by a shuffle tree), a lane the
+// channels lane, lane + 64, ... (C <= 64 * 24); one atomic per channel and wave at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_affine_grad_kernel(const T* __restrict__ x, const T* __restrict__ dy, int M, int C, float eps, int rows_per_wave,
+                                                             float* g_gamma, float* g_beta) {
+    constexpr int MAXC = 24;
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = wave * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
+    float ag[MAXC], ab[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) ag[i] = ab[i] = 0.f;
+    const int nc = (C + 63) / 64;
+    for (int r = r0; r < r1; ++r) {
+        float v[MAXC];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (i < nc && c < C) ? to_f32(x[(size_t)r * C + c]) : 0.f;
+            s1 += v[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+        const float mu = s1 / C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (i < nc && c < C) { const float d = v[i] - mu; s2 += d * d; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        const float rs = rsqrtf(s2 / C + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (i < nc && c < C) {
+                const float d = to_f32(dy[(size_t)r * C + c]);
+                ag[i] += d * (v[i] - mu) * rs;
+                ab[i] += d;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nc && c < C && r0 < r1) { atomicAdd(g_gamma + c, ag[i]); atomicAdd(g_beta + c, ab[i]); }
+    }
+}
+template <typename T>
+int launch_ln_affine_grad(const void* x, const void* dy, int M, int C, float eps, float* g_gamma, float* g_beta, hipStream_t st) {
+    MRISR_REQUIRE(C <= 64 * 24, "LayerNorm affine gradient: row width");
+    const int rpw = 32, waves = (M + rpw - 1) / rpw;
+    hipLaunchKernelGGL(ln_affine_grad_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, st, reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), M, C, eps,
+                       rpw, g_gamma, g_beta);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// out[b][off + c] += sum_hw dh[b][hw][c]  (the time-embedding projection enters a ResnetBlock as a per-image row vector); div = HW for
+// per-sample timesteps, one row for a scalar timestep (rows = 1: every image adds into row 0)
+template <typename T>
+__global__ __launch_bounds__(256) void rowvec_grad_kernel(const T* __restrict__ dh, float* out, int ld_out, int off, int HW, int C, int scalar_t) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int r = sub; r < HW; r += 4) acc += to_f32(dh[((size_t)b * HW + r) * C + c]);
+    red[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && c < C) atomicAdd(out + (size_t)(scalar_t ? 0 : b) * ld_out + off + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <typename T>
+int launch_rowvec_grad(const void* dh, float* out, int ld_out, int off, int B, int HW, int C, int scalar_t, hipStream_t st) {
+    hipLaunchKernelGGL(rowvec_grad_kernel<T>, dim3(B, (C + 63) / 64), dim3(256), 0, st, reinterpret_cast<const T*>(dh), out, ld_out, off, HW, C, scalar_t);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// tiny dense layers of the time-embedding MLP (rows <= 64), f32 activations, weights of type T:
+//   small_wgrad:  gW[n][k] += sum_r dY[r][n] act(X[r][k]),  gB[n] += sum_r dY[r][n]          (act = SiLU when silu_in)
+//   small_dgrad:  dX[r][k]  = (sum_n dY[r][n] W[n][k]) * (pre ? silu'(pre[r][k]) : 1)
+__global__ void small_wgrad_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int rows, int N, int K, int silu_in,
+                                   float* gW, float* gB) {
+    const long long total = (long long)N * K;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+        float acc = 0.f, accb = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            float xv = X[(size_t)r * ldx + k];
+            if (silu_in) xv = silu_f(xv);
+            const float d = dY[(size_t)r * ldy + n];
+            acc += d * xv;
+            accb += d;
+        }
+        gW[i] += acc;
+        if (k == 0 && gB) gB[n] += accb;
+    }
+}
+template <typename T>
+__global__ void small_dgrad_kernel(const float* __restrict__ dY, int ldy, const T* __restrict__ W, int rows, int N, int K, const float* __restrict__ pre,
+                                   int ldpre, float* dX, int ldx) {
+    const long long total = (long long)rows * K;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / K), k = (int)(i - (long long)r * K);
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += dY[(size_t)r * ldy + n] * to_f32(W[(size_t)n * K + k]);
+        if (pre) acc *= silu_grad(pre[(size_t)r * ldpre + k]);
+        dX[(size_t)r * ldx + k] = acc;
+    }
+}
+int launch_small_wgrad(const float* dY, int ldy, const float* X, int ldx, int rows, int N, int K, int silu_in, float* gW, float* gB, hipStream_t st) {
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3(bw_blocks((long long)N * K)), dim3(256), 0, st, dY, ldy, X, ldx, rows, N, K, silu_in, gW, gB);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <typename T>
+int launch_small_dgrad(const float* dY, int ldy, const void* W, int rows, int N, int K, const float* pre, int ldpre, float* dX, int ldx, hipStream_t st) {
+    hipLaunchKernelGGL(small_dgrad_kernel<T>, dim3(bw_blocks((long long)rows * K)), dim3(256), 0, st, dY, ldy, reinterpret_cast<const T*>(W), rows, N, K, pre,
+                       ldpre, dX, ldx);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+#define AFF_INST(T)                                                                                                                                              \
+    template int launch_gn_affine_grad<T>(const void*, const void*, const float*, const float*, const float*, int, int, int, int, int, float, int, float*, float*, \
+                                          hipStream_t);                                                                                                          \
+    template int launch_ln_affine_grad<T>(const void*, const void*, int, int, float, float*, float*, hipStream_t);                                               \
+    template int launch_rowvec_grad<T>(const void*, float*, int, int, int, int, int, int, hipStream_t);                                                          \
+    template int launch_small_dgrad<T>(const float*, int, const void*, int, int, int, const float*, int, float*, int, hipStream_t);
+AFF_INST(float)
+AFF_INST(bf16)
+#undef AFF_INST
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_accum_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, tmp, gw, n, taps, tap);
     MRISR_CHECK_HIP(hipGetLastError());

@@ -250,6 +250,14 @@ int launch_wgrad_accum_all(const float* tmp, float* gw, int Cout, int Cin, int t
 int launch_wgrad_accum_gen(const float* tmp, int ld_tmp, int cin_src, float* gw, int Cout, int Cin, int taps, int geglu_half, hipStream_t st);
 template <typename T> int launch_colsum_gen(const void* dy, int ld, int col0, float* out, int M, int C, int geglu_half, hipStream_t st);
 template <typename T>
+int launch_gn_affine_grad(const void* x, const void* dy, const float* gamma, const float* beta, const float* fwd_partial, int nsplit, int groups, int B, int HW,
+                          int C, float eps, int silu, float* g_gamma, float* g_beta, hipStream_t st);
+template <typename T> int launch_ln_affine_grad(const void* x, const void* dy, int M, int C, float eps, float* g_gamma, float* g_beta, hipStream_t st);
+template <typename T> int launch_rowvec_grad(const void* dh, float* out, int ld_out, int off, int B, int HW, int C, int scalar_t, hipStream_t st);
+int launch_small_wgrad(const float* dY, int ldy, const float* X, int ldx, int rows, int N, int K, int silu_in, float* gW, float* gB, hipStream_t st);
+template <typename T>
+int launch_small_dgrad(const float* dY, int ldy, const void* W, int rows, int N, int K, const float* pre, int ldpre, float* dX, int ldx, hipStream_t st);
+template <typename T>
 int launch_im2col_all_T(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, int ks, int Mpad,
                         hipStream_t st);
 template <typename T> int launch_pack_conv_dgrad(const float* w, void* wd, int Cout, int Cin, hipStream_t st);

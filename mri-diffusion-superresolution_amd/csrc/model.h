@@ -72,6 +72,8 @@ struct Model {
     bool keep = false;  // training forward: never release arena temporaries (the backward reads them)
     // per-forward state
     float* tproj_out = nullptr;
+    float *te_s = nullptr, *te_y1 = nullptr, *te_emb = nullptr;  // the time-embedding MLP's activations of this forward (training reads them)
+    float* d_tproj = nullptr;                                     // full-parameter training: d(loss)/d(tproj_out), [rows][tproj_total]
     int t_scalar = 1;
 
     int set_param(const char* key, const float* data, const int64_t* shape, int ndim, int is_device);

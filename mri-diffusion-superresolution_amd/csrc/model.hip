@@ -82,6 +82,7 @@ struct Packer {
     }
     NormW norm(const std::string& name) {
         NormW n;
+        n.name = name;
         n.g = f32(name + ".weight");
         n.b = f32(name + ".bias");
         if (n.g) n.c = (int)m.find(name + ".weight")->shape[0];

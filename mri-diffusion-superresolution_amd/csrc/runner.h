@@ -366,6 +366,7 @@ struct Runner {
         m.tproj_out = static_cast<float*>(alloc((size_t)rows * m.tproj_total * sizeof(float)));
         if (!s || !y1 || !emb || !m.tproj_out) return 7;
         m.t_scalar = t_scalar;
+        m.te_s = s; m.te_y1 = y1; m.te_emb = emb;
         if (dry) return 0;
         TRY(launch_timestep_embedding(t_dev, t_scalar, s, rows, c0, st));
         TRY(launch_gemv_rows<T>(s, c0, m.te1.w, m.te1.b, y1, temb, rows, temb, c0, 0, st));

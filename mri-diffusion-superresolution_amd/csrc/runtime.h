@@ -65,6 +65,7 @@ struct NormW {
     const float* g = nullptr;
     const float* b = nullptr;
     int c = 0;
+    std::string name;  // state-dict module name (full-parameter training writes its affine gradients by name)
 };
 struct ConvW {  // packed [cout][ks*ks*cin] in compute dtype, bias f32
     void* w = nullptr;

@@ -285,6 +285,48 @@ struct Trainer : Runner<T> {
         return 0;
     }
 
+    // affine parameters of a GroupNorm(+SiLU) / LayerNorm (dy: gradient with respect to the norm's OUTPUT)
+    int gn_affine(const Act& x, const void* dy, const NormW& nw, bool silu, float eps, const float* fwd_partial, int nsplit) {
+        if (!full() || dry) return 0;
+        float* gg = gptr(nw.name + ".weight");
+        float* gb = gptr(nw.name + ".bias");
+        MRISR_REQUIRE(gg && gb && nw.c == x.C, "GroupNorm affine gradient: parameters");
+        return launch_gn_affine_grad<T>(x.p, dy, nw.g, nw.b, fwd_partial, nsplit, m.cfg.norm_num_groups, x.B, x.H * x.W, x.C, eps, silu ? 1 : 0, gg, gb, st);
+    }
+    int ln_affine(const void* x, const void* dy, const NormW& nw, int M, int C) {
+        if (!full() || dry) return 0;
+        float* gg = gptr(nw.name + ".weight");
+        float* gb = gptr(nw.name + ".bias");
+        MRISR_REQUIRE(gg && gb, "LayerNorm affine gradient: parameters");
+        return launch_ln_affine_grad<T>(x, dy, M, C, 1e-5f, gg, gb, st);
+    }
+    // the time-embedding path, after every ResnetBlock has added its share to m.d_tproj:  tproj_out = Wp silu(emb) + bp,
+    // emb = W2 silu(y1) + b2,  y1 = W1 s + b1  (Runner::time_embed); rows = 1 (scalar timestep) or B
+    int time_embed_bwd(int B) {
+        if (!full()) return 0;
+        const int rows = m.t_scalar ? 1 : B, c0 = m.cfg.block_out_channels[0], temb = 4 * c0;
+        const size_t mk = m.arena.mark();
+        float* d_emb = static_cast<float*>(alloc((size_t)rows * temb * sizeof(float)));
+        float* d_y1 = static_cast<float*>(alloc((size_t)rows * temb * sizeof(float)));
+        if (!d_emb || !d_y1) return 7;
+        if (!dry) {
+            int off = 0;
+            for (auto& mod : m.temb_mods) {
+                const RawParam* w = m.find(mod + ".weight");
+                MRISR_REQUIRE(w, "time_emb_proj weight");
+                const int n = (int)w->shape[0];
+                TRY(launch_small_wgrad(m.d_tproj + off, m.tproj_total, m.te_emb, temb, rows, n, temb, 1, gptr(mod + ".weight"), gptr(mod + ".bias"), st));
+                off += n;
+            }
+            TRY(launch_small_dgrad<T>(m.d_tproj, m.tproj_total, m.tproj.w, rows, m.tproj_total, temb, m.te_emb, temb, d_emb, temb, st));
+            TRY(launch_small_wgrad(d_emb, temb, m.te_y1, temb, rows, temb, temb, 1, gptr("time_embedding.linear_2.weight"), gptr("time_embedding.linear_2.bias"), st));
+            TRY(launch_small_dgrad<T>(d_emb, temb, m.te2.w, rows, temb, temb, m.te_y1, temb, d_y1, temb, st));
+            TRY(launch_small_wgrad(d_y1, temb, m.te_s, c0, rows, temb, c0, 0, gptr("time_embedding.linear_1.weight"), gptr("time_embedding.linear_1.bias"), st));
+        }
+        m.arena.release(mk);
+        return 0;
+    }
+
     // dX (+)= conv3x3(dY, wd).  mode 1: the forward conv had stride 2 -> dY is zero-stuffed to twice its size
     int conv_dgrad(const Act& dy, const ConvW& cw, int mode, void* out, bool acc) {
         MRISR_REQUIRE(cw.wd && dy.C == cw.cout, "conv dgrad weights");
@@ -575,13 +617,17 @@ struct Trainer : Runner<T> {
             if (!dhn.p || !dh.p || !dxn.p) return 7;
             TRY(wgrad_conv(hn, dOa, rr.c2, 1));
             TRY(conv_dgrad(dOa, rr.c2, 0, dhn.p, false));
+            TRY(gn_affine(h, dhn.p, rr.n2, true, m.cfg.norm_eps, p2, ns2));
             TRY(gn_bwd(h, nullptr, rr.n2, true, m.cfg.norm_eps, p2, ns2, dhn.p, dh.p, false, nullptr, false));
+            if (full() && m.d_tproj && !dry)  // h = conv1(.) + time_emb_proj(silu(emb))[:, :, None, None]: its gradient is the per-image sum of dh
+                TRY(launch_rowvec_grad<T>(dh.p, m.d_tproj, m.tproj_total, rr.temb_off, o.B, o.H * o.W, rr.cout, m.t_scalar, st));
             TRY(wgrad_conv(xn, dh, rr.c1, 1));
             if (full() && rr.has_sc) {
                 MRISR_REQUIRE(!has_x1, "full-parameter training: single-source shortcut");
                 TRY(wgrad_linear(rr.sc, x.p, x.C, dO, rr.cout, (int)x.rows()));
             }
             TRY(conv_dgrad(dh, rr.c1, 0, dxn.p, false));
+            if (!has_x1) TRY(gn_affine(x, dxn.p, rr.n1, true, m.cfg.norm_eps, p1, ns1));
             TRY(gn_bwd(x, has_x1 ? &x1v : nullptr, rr.n1, true, m.cfg.norm_eps, p1, ns1, dxn.p, s0.g, s0.written,
                        s1 ? s1->g : nullptr, s1 ? s1->written : false));
             s0.written = true;
@@ -682,21 +728,25 @@ struct Trainer : Runner<T> {
             TRY(linear_bwd(w.ff2, ff, 4 * C, z_f2, dt, C, M, dff, false, true));
             if (!dry) TRY(launch_geglu_bwd<T>(ffpre, dff, dpre, M, 4 * C, st));
             TRY(linear_bwd(w.ff1, n3, C, nullptr, dpre, 8 * C, M, dn, false, true));
+            TRY(ln_affine(t2, dn, w.ln3, M, C));
             if (!dry) TRY(launch_layernorm_bwd<T>(t2, dn, dt, w.ln3.g, M, C, 1e-5f, 1, st));
             // t2 = t1 + out2(attn(q2(LN2(t1)), K_ctx, V_ctx))
             TRY(linear_bwd(w.out2, ao2, C, z_o2, dt, C, M, dao, false, true));
             TRY(attention_bwd(hbv, a2, dao, dq, C, dkv, dkv ? dkv + C : nullptr, 2 * C));
             if (dkv) TRY(linear_bwd(w.kv2, m.ctx_rows, m.cfg.cross_attention_dim, zkv, dkv, 2 * C, Bc, nullptr, false, false));
             TRY(linear_bwd(w.q2, n2, C, z_q2, dq, C, M, dn, false, true));
+            TRY(ln_affine(t1, dn, w.ln2, M, C));
             if (!dry) TRY(launch_layernorm_bwd<T>(t1, dn, dt, w.ln2.g, M, C, 1e-5f, 1, st));
             // t1 = t0 + out1(attn(qkv(LN1(t0))))
             TRY(linear_bwd(w.out1, ao1, C, z_o1, dt, C, M, dao, false, true));
             TRY(attention_bwd(hbv, a1, dao, dqkv, 3 * C, dqkv + C, dqkv + 2 * C, 3 * C));
             TRY(linear_bwd(w.qkv, n1, C, z_qkv, dqkv, 3 * C, M, dn, false, true));
+            TRY(ln_affine(t0, dn, w.ln1, M, C));
             if (!dry) TRY(launch_layernorm_bwd<T>(t0, dn, dt, w.ln1.g, M, C, 1e-5f, 1, st));
             // t0 = proj_in(GN(x))
             if (sx) {
                 TRY(linear_bwd(w.proj_in, xn.p, C, z_pi, dt, C, M, dn, false, true));
+                TRY(gn_affine(x, dn, w.norm, false, 1e-6f, gp, gns));
                 TRY(gn_bwd(x, nullptr, w.norm, false, 1e-6f, gp, gns, dn, sx->g, sx->written, nullptr, false));
                 sx->written = true;
                 if (!dry) TRY(launch_add_inplace<T>(sx->g, dO, (long long)x.numel(), st));
@@ -801,6 +851,7 @@ struct Trainer : Runner<T> {
     // ---------------------------------------------------------------------------------------------
     std::vector<Act> cn_skips;
     Act cn_x;  // mid-block output
+    int cn_B = 0;
     int cn_forward(const mrisr_tensor& sample, const long long* t_dev, int t_scalar, const mrisr_tensor& ehs, const mrisr_tensor& cond, float scale,
                    mrisr_tensor* down_out, int n_down, mrisr_tensor* mid_out) {
         m.arena.reset();
@@ -808,6 +859,12 @@ struct Trainer : Runner<T> {
         TRY(set_context_t(ehs));
         TRY(R::set_cond(cond));  // (the condition embedding's own gradients: not differentiated yet - reported in full_unsupported)
         TRY(R::time_embed(t_dev, t_scalar, B));
+        {
+            const size_t nb = (size_t)(t_scalar ? 1 : B) * m.tproj_total * sizeof(float);
+            m.d_tproj = static_cast<float*>(alloc(nb));
+            TRY(zero(m.d_tproj, nb));
+        }
+        cn_B = B;
         Act s, x;
         TRY(R::import_act(sample, &s, false));
         Act ce;
@@ -897,7 +954,7 @@ struct Trainer : Runner<T> {
             m.arena.release(mk);
         }
         for (size_t i = tape.size(); i-- > 0;) TRY(tape[i]());
-        return 0;
+        return time_embed_bwd(cn_B);
     }
 
     int step(const mrisr_tensor& sample, const long long* t_dev, int t_scalar, const mrisr_tensor& ehs, const mrisr_tensor* intrablock,
@@ -1105,11 +1162,12 @@ int Model::full_train_prepare(hipStream_t st) {
         full_off[kv.first] = off;
         full_trainables.push_back({kv.first, off, r.numel(), (int)rows, (int)(r.numel() / (rows ? rows : 1))});
         off += r.numel();
-        // what this build differentiates: every conv / linear weight and bias of the encoder, mid block and zero convs.  Still frozen
-        // (gradient left at zero): norm affine parameters, the time-embedding MLP and its per-block projections, the condition embedding
+        // what this build differentiates: every conv / linear weight and bias of the encoder, mid block and zero convs, the affine
+        // parameters of every norm, the time-embedding MLP and its per-block projections.  Still frozen (gradient left at zero): the
+        // condition embedding
         const std::string& k = kv.first;
         auto has = [&](const char* s) { return k.find(s) != std::string::npos; };
-        if (has("norm") || has("time_emb") || has("controlnet_cond_embedding")) full_unsupported.push_back(k);
+        if (has("controlnet_cond_embedding")) full_unsupported.push_back(k);
     }
     n_full = off;
     return cfg.compute_dtype == MRISR_F32 ? full_train_prepare_t<float>(*this, st) : full_train_prepare_t<bf16>(*this, st);

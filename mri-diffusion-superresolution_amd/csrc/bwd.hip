@@ -1393,6 +1393,52 @@ int launch_small_dgrad(const float* dY, int ldy, const void* W, int rows, int N,
 AFF_INST(float)
 AFF_INST(bf16)
 #undef AFF_INST
+// SiLU as its own pass (the ControlNet condition embedding in training keeps the pre-activations), and its backward
+template <typename T>
+__global__ void silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = from_f32<T>(silu_f(to_f32(x[i])));
+}
+template <typename T>
+__global__ void silu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dx[i] = from_f32<T>(to_f32(dy[i]) * silu_grad(to_f32(pre[i])));
+}
+template <typename T>
+int launch_silu_fwd(const void* x, void* y, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(silu_fwd_kernel<T>, dim3(bw_blocks(n)), dim3(256), 0, st, reinterpret_cast<const T*>(x), reinterpret_cast<T*>(y), n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <typename T>
+int launch_silu_bwd(const void* dy, const void* pre, void* dx, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(silu_bwd_kernel<T>, dim3(bw_blocks(n)), dim3(256), 0, st, reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(pre), reinterpret_cast<T*>(dx), n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// dgrad bank of a zero-padded 3x3 conv: wd[ci][ky][kx][co] over the PADDED channel counts, zero outside the raw tensor
+template <typename T>
+__global__ void pack_conv_dgrad_padded_kernel(const float* __restrict__ w, T* __restrict__ wd, int Cout, int Cin, int Cout_p, int Cin_p) {
+    const long long total = (long long)Cout_p * Cin_p * 9;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Cout_p);
+        const int t = (int)((i / Cout_p) % 9);
+        const int ci = (int)(i / (9ll * Cout_p));
+        const int ky = t / 3, kx = t - ky * 3;
+        wd[i] = from_f32<T>(co < Cout && ci < Cin ? w[(((size_t)co * Cin + ci) * 3 + (2 - ky)) * 3 + (2 - kx)] : 0.f);
+    }
+}
+template <typename T>
+int launch_pack_conv_dgrad_padded(const float* w, void* wd, int Cout, int Cin, int Cout_p, int Cin_p, hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv_dgrad_padded_kernel<T>, dim3(bw_blocks((long long)Cout_p * Cin_p * 9)), dim3(256), 0, st, w, reinterpret_cast<T*>(wd), Cout, Cin, Cout_p, Cin_p);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+#define SILU_INST(T)                                                                    \
+    template int launch_silu_fwd<T>(const void*, void*, long long, hipStream_t);        \
+    template int launch_silu_bwd<T>(const void*, const void*, void*, long long, hipStream_t); \
+    template int launch_pack_conv_dgrad_padded<T>(const float*, void*, int, int, int, int, hipStream_t);
+SILU_INST(float)
+SILU_INST(bf16)
+#undef SILU_INST
 int launch_wgrad_accum(const float* tmp, float* gw, long long n, int taps, int tap, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_accum_kernel, dim3(bw_blocks(n)), dim3(256), 0, st, tmp, gw, n, taps, tap);
     MRISR_CHECK_HIP(hipGetLastError());

@@ -254,6 +254,9 @@ int launch_gn_affine_grad(const void* x, const void* dy, const float* gamma, con
                           int C, float eps, int silu, float* g_gamma, float* g_beta, hipStream_t st);
 template <typename T> int launch_ln_affine_grad(const void* x, const void* dy, int M, int C, float eps, float* g_gamma, float* g_beta, hipStream_t st);
 template <typename T> int launch_rowvec_grad(const void* dh, float* out, int ld_out, int off, int B, int HW, int C, int scalar_t, hipStream_t st);
+template <typename T> int launch_silu_fwd(const void* x, void* y, long long n, hipStream_t st);
+template <typename T> int launch_silu_bwd(const void* dy, const void* pre, void* dx, long long n, hipStream_t st);
+template <typename T> int launch_pack_conv_dgrad_padded(const float* w, void* wd, int Cout, int Cin, int Cout_p, int Cin_p, hipStream_t st);
 int launch_small_wgrad(const float* dY, int ldy, const float* X, int ldx, int rows, int N, int K, int silu_in, float* gW, float* gB, hipStream_t st);
 template <typename T>
 int launch_small_dgrad(const float* dY, int ldy, const void* W, int rows, int N, int K, const float* pre, int ldpre, float* dX, int ldx, hipStream_t st);

@@ -241,15 +241,16 @@ struct Trainer : Runner<T> {
     int wgrad(const void* x, int xB, int xH, int xW, int cin_src, const void* dY, int ldy, int col0, int Ho, int Wo, int cout_src, int ks,
               int stride, float* gW, float* gB, int cout, int cin, int geglu_half = 0) {
         const int M = xB * Ho * Wo, Mpad = (M + 63) / 64 * 64, taps = ks * ks;
+        const int ncol = (taps * cin_src + 3) & ~3;  // the GEMM's N in multiples of 4 (3-channel images: 27 -> 28, one zero column)
         const size_t mk = m.arena.mark();
         T* dyT = static_cast<T*>(alloc((size_t)cout_src * Mpad * sizeof(T)));
-        T* xT = static_cast<T*>(alloc((size_t)taps * cin_src * Mpad * sizeof(T)));
-        float* tmp = static_cast<float*>(alloc((size_t)cout_src * taps * cin_src * sizeof(float)));
+        T* xT = static_cast<T*>(alloc((size_t)ncol * Mpad * sizeof(T)));
+        float* tmp = static_cast<float*>(alloc((size_t)cout_src * ncol * sizeof(float)));
         if (!dyT || !xT || !tmp) return 7;
         if (!dry) {
-            if (Mpad != M) {
+            if (Mpad != M || ncol != taps * cin_src) {
                 MRISR_CHECK_HIP(hipMemsetAsync(dyT, 0, (size_t)cout_src * Mpad * sizeof(T), st));
-                MRISR_CHECK_HIP(hipMemsetAsync(xT, 0, (size_t)taps * cin_src * Mpad * sizeof(T), st));
+                MRISR_CHECK_HIP(hipMemsetAsync(xT, 0, (size_t)ncol * Mpad * sizeof(T), st));
             }
             TRY(launch_transpose<T>(static_cast<const T*>(dY) + col0, dyT, M, cout_src, ldy, Mpad, 0, 0, 1, M, st));
             if (gB) TRY(launch_colsum_gen<T>(dY, ldy, col0, gB, M, cout, geglu_half, st));
@@ -257,10 +258,10 @@ struct Trainer : Runner<T> {
         }
         GemmArgs g;
         g.a0 = dyT; g.c0 = Mpad; g.lda0 = Mpad;
-        g.w = xT; g.M = cout_src; g.N = taps * cin_src; g.K = Mpad;
-        g.out_mode = OUT_F32; g.out = tmp; g.ldo = taps * cin_src;
+        g.w = xT; g.M = cout_src; g.N = ncol; g.K = Mpad;
+        g.out_mode = OUT_F32; g.out = tmp; g.ldo = ncol;
         TRY(R::run_gemm(g));
-        if (!dry && gW) TRY(launch_wgrad_accum_gen(tmp, taps * cin_src, cin_src, gW, cout, cin, taps, geglu_half, st));
+        if (!dry && gW) TRY(launch_wgrad_accum_gen(tmp, ncol, cin_src, gW, cout, cin, taps, geglu_half, st));
         m.arena.release(mk);
         return 0;
     }
@@ -849,6 +850,65 @@ struct Trainer : Runner<T> {
     // ControlNet with every parameter trainable (full-parameter mode).  Forward = Runner::controlnet_forward's sequence, recorded;
     // the backward is seeded with d(loss)/d(residual k) - what the UNet's step exported (mrisr_train_set_controlnet_residuals).
     // ---------------------------------------------------------------------------------------------
+    // ControlNet condition embedding (App. A.6: conv_in, six blocks, conv_out; SiLU after all but the last) with the pre-activations kept
+    // - the inference path fuses the SiLU into the conv epilogue and caches only the result.  Layers 1.. run zero-padded to 64-channel
+    // multiples (model.hip conv_padded): gradients flow through the padded banks, the raw tensors receive their sub-blocks.
+    std::vector<Act> ce_in, ce_pre;
+    int set_cond_t(const mrisr_tensor& cond) {
+        Act e, y;
+        TRY(R::import_act(cond, &e, false));
+        ce_in.clear();
+        ce_pre.clear();
+        for (size_t k = 0; k < m.ce.size(); ++k) {
+            const bool last = k + 1 == m.ce.size();
+            constexpr int KQ = 128 / (int)sizeof(T);
+            ce_in.push_back(e);
+            if (e.C % KQ == 0 && m.ce[k].cout % 4 == 0) TRY(R::conv3(e, nullptr, m.ce[k], m.ce_stride[k], 0, nullptr, 0, 1, nullptr, ACT_NONE, &y));
+            else TRY(R::direct(e, m.ce[k], m.ce_stride[k], ACT_NONE, nullptr, &y));
+            ce_pre.push_back(y);
+            if (!last) {
+                Act a = new_act(y.B, y.H, y.W, y.C);
+                if (!a.p) return 7;
+                if (!dry) TRY(launch_silu_fwd<T>(y.p, a.p, (long long)y.numel(), st));
+                e = a;
+            } else {
+                e = y;
+            }
+        }
+        MRISR_REQUIRE(e.numel() * sizeof(T) <= m.cond_emb_bytes, "condition embedding larger than planned");
+        if (!dry) MRISR_CHECK_HIP(hipMemcpyAsync(m.cond_emb, e.p, e.numel() * sizeof(T), hipMemcpyDeviceToDevice, st));
+        m.cond_valid = false;  // (the cache holds THIS step's weights only)
+        return 0;
+    }
+    int set_cond_bwd(const Act& d_ce) {  // d_ce: gradient with respect to the embedding = the gradient of conv_in's output
+        const size_t mk = m.arena.mark();
+        Act dcur = d_ce;
+        for (size_t kk = m.ce.size(); kk-- > 0;) {
+            const ConvW& cw = m.ce[kk];
+            const bool last = kk + 1 == m.ce.size();
+            const Act& pre = ce_pre[kk];
+            const Act& xin = ce_in[kk];
+            Act dpre = dcur;
+            if (!last) {
+                dpre = new_act(pre.B, pre.H, pre.W, pre.C);
+                if (!dpre.p) return 7;
+                if (!dry) TRY(launch_silu_bwd<T>(dcur.p, pre.p, dpre.p, (long long)pre.numel(), st));
+            }
+            const RawParam* w = m.find(cw.name + ".weight");
+            MRISR_REQUIRE(w && dpre.C == cw.cout && xin.C == cw.cin, "condition-embedding gradient: operands");
+            TRY(wgrad(xin.p, xin.B, xin.H, xin.W, xin.C, dpre.p, dpre.C, 0, dpre.H, dpre.W, dpre.C, cw.ks, m.ce_stride[kk], gptr(cw.name + ".weight"),
+                      gptr(cw.name + ".bias"), (int)w->shape[0], (int)w->shape[1]));
+            if (kk > 0) {
+                Act dx = new_act(xin.B, xin.H, xin.W, xin.C);
+                if (!dx.p) return 7;
+                TRY(conv_dgrad(dpre, cw, m.ce_stride[kk] == 2 ? 1 : 0, dx.p, false));
+                dcur = dx;
+            }
+        }
+        m.arena.release(mk);
+        return 0;
+    }
+
     std::vector<Act> cn_skips;
     Act cn_x;  // mid-block output
     int cn_B = 0;
@@ -857,7 +917,7 @@ struct Trainer : Runner<T> {
         m.arena.reset();
         const int B = (int)sample.shape[0];
         TRY(set_context_t(ehs));
-        TRY(R::set_cond(cond));  // (the condition embedding's own gradients: not differentiated yet - reported in full_unsupported)
+        TRY(set_cond_t(cond));
         TRY(R::time_embed(t_dev, t_scalar, B));
         {
             const size_t nb = (size_t)(t_scalar ? 1 : B) * m.tproj_total * sizeof(float);
@@ -877,7 +937,8 @@ struct Trainer : Runner<T> {
                 auto it = slots.find(xv.p);
                 MRISR_REQUIRE(it != slots.end() && it->second.written, "conv_in output has no gradient");
                 Act dy = xv; dy.p = it->second.g;
-                return wgrad_conv(sv, dy, m.conv_in, 1);
+                TRY(wgrad_conv(sv, dy, m.conv_in, 1));
+                return set_cond_bwd(dy);  // x = conv_in(sample) + embedding: the embedding's gradient is the same tensor
             });
         }
         cn_skips.clear();
@@ -1145,6 +1206,14 @@ static int full_train_prepare_t(Model& m, hipStream_t st) {
     for (LinW* l : {&m.mid_xf.proj_in, &m.mid_xf.qkv, &m.mid_xf.out1, &m.mid_xf.q2, &m.mid_xf.out2, &m.mid_xf.ff1, &m.mid_xf.ff2, &m.mid_xf.proj_out}) lin_t(*l);
     for (auto& l : m.cn_down) lin_t(l);
     lin_t(m.cn_mid);
+    for (size_t k = 1; k < m.ce.size(); ++k) {  // condition embedding: zero-padded dgrad banks (layer 0 needs no input gradient)
+        ConvW& c = m.ce[k];
+        const RawParam* w = m.find(c.name + ".weight");
+        if (!w || c.ks != 3) { err = 3; set_error("condition embedding: missing / unexpected layer " + c.name); break; }
+        if (!c.wd) c.wd = m.new_packed((size_t)c.cout * c.cin * 9 * sizeof(T), false);
+        if (!c.wd) { err = 4; break; }
+        if (launch_pack_conv_dgrad_padded<T>(static_cast<const float*>(w->data->p), c.wd, (int)w->shape[0], (int)w->shape[1], c.cout, c.cin, st)) err = 5;
+    }
     MRISR_CHECK_HIP(hipGetLastError());
     return err;
 }
@@ -1163,11 +1232,10 @@ int Model::full_train_prepare(hipStream_t st) {
         full_trainables.push_back({kv.first, off, r.numel(), (int)rows, (int)(r.numel() / (rows ? rows : 1))});
         off += r.numel();
         // what this build differentiates: every conv / linear weight and bias of the encoder, mid block and zero convs, the affine
-        // parameters of every norm, the time-embedding MLP and its per-block projections.  Still frozen (gradient left at zero): the
-        // condition embedding
+        // parameters of every norm, the time-embedding MLP and its per-block projections, the condition embedding - everything
         const std::string& k = kv.first;
         auto has = [&](const char* s) { return k.find(s) != std::string::npos; };
-        if (has("controlnet_cond_embedding")) full_unsupported.push_back(k);
+        (void)has;  // (every tensor is differentiated; full_unsupported stays empty)
     }
     n_full = off;
     return cfg.compute_dtype == MRISR_F32 ? full_train_prepare_t<float>(*this, st) : full_train_prepare_t<bf16>(*this, st);

@@ -72,7 +72,7 @@ def test_controlnet_weight_gradients_match_autograd(tiny, dt, tol):
             print(f"   {k:90s} {errs[k]:.3e}  |g| {float(g[k].norm()):.3e} ref {float(cpg[k].grad.norm()):.3e}")
     for k in frozen:  # documented gaps: left at exactly zero, never garbage
         assert float(g[k].abs().max()) == 0.0, k
-    assert all("controlnet_cond_embedding" in k for k in frozen), sorted(frozen)[:5]
+    assert not frozen, sorted(frozen)[:5]   # every one of the ControlNet's tensors is differentiated
     if dt == "f32":
         assert worst[0][1] < 1e-3, worst
     else:

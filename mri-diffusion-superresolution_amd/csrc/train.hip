@@ -1257,10 +1257,19 @@ int Model::full_train_refresh(hipStream_t st) {
     MRISR_REQUIRE(full_theta, "bind the trainable vector first");
     for (auto& t : full_trainables)
         MRISR_CHECK_HIP(hipMemcpyAsync(raw.at(t.key).data->p, full_theta + t.offset, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, st));
-    TRY(repack(st));
+    // re-pack INTO the existing buffers: the forward copies (finalize) and, still in the same buffer sequence, the dgrad copies
+    repacking = true;
+    repack_cursor = 0;
+    int rc = finalize(st);
+    if (!rc) rc = cfg.compute_dtype == MRISR_F32 ? full_train_prepare_t<float>(*this, st) : full_train_prepare_t<bf16>(*this, st);
+    repacking = false;
+    // finalize rebuilt the module structs: the per-block workspace pointers planned into them (cached context K / V^T, ...) are gone ->
+    // plan again at the next forward (same sizes: no allocation, the dry passes only)
+    ws_key.clear();
+    train_ws_key.clear();
     cond_valid = false;
     ctx_valid = false;
-    return cfg.compute_dtype == MRISR_F32 ? full_train_prepare_t<float>(*this, st) : full_train_prepare_t<bf16>(*this, st);
+    return rc;
 }
 
 template <typename T>

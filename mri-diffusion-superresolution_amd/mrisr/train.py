@@ -280,6 +280,38 @@ class LoRATrainer(_FlatAdamW):
         return loss
 
 
+def _numel(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+def controlnet_bucket_ranges(layout: Sequence[Tuple[str, int, int]]) -> List[Tuple[str, int, int]]:
+    """``layout``: (key, offset, numel) of a ControlNet's flat parameter vector (offsets in sorted-key order, as the library lays
+    them out).  Returns (group, lo, hi) in backward-finalisation order; the groups tile [0, total) exactly."""
+    def group(k: str) -> str:
+        if k.startswith("controlnet_down_blocks.") or k.startswith("controlnet_mid_block."):
+            return "zero_convs"
+        if k.startswith("down_blocks."):
+            return "down_blocks." + k.split(".")[1]
+        for g in ("mid_block", "conv_in", "controlnet_cond_embedding", "time_embedding"):
+            if k.startswith(g + "."):
+                return g
+        raise KeyError(f"not a ControlNet parameter: {k}")
+    spans: Dict[str, List[int]] = {}
+    for k, o, n in layout:
+        g = group(k)
+        lo, hi = spans.get(g, [o, o + n])
+        spans[g] = [min(lo, o), max(hi, o + n)]
+    # sorted keys put controlnet_down_blocks.* and controlnet_mid_block.* side by side, and every other group in one run
+    total = sum(n for _, _, n in layout)
+    assert sum(hi - lo for lo, hi in spans.values()) == total, "groups must be contiguous runs of the sorted-key layout"
+    levels = sorted((g for g in spans if g.startswith("down_blocks.")), key=lambda g: -int(g.split(".")[1]))
+    order = ["zero_convs", "mid_block"] + levels + ["conv_in", "controlnet_cond_embedding", "time_embedding"]
+    return [(g, spans[g][0], spans[g][1]) for g in order if g in spans]
+
+
 class ControlNetTrainer(_FlatAdamW):
     """A ``ControlNetModel`` with its own parameters trainable (the reference itself only runs a ControlNet for
     inference, res_srdiff.py:65-70).  All raw tensors live in one flat f32 vector (``self.theta``; ``self.layout`` maps state-dict keys
@@ -365,6 +397,27 @@ class ControlNetTrainer(_FlatAdamW):
         arr = L.tensor_array([L.as_tensor(d) for d in g])
         t_m = L.as_tensor(gm)
         L.check(L.lib().mrisr_controlnet_train_backward(cn._h, arr, len(g), C.byref(t_m), C.c_float(self.scale), L.stream_ptr()))
+
+    def bucket_ranges(self) -> List[Tuple[str, int, int]]:
+        """Contiguous ranges [lo, hi) of the flat vector in the order in which the backward FINALISES them - what
+        ``mrisr.dist.BucketedReducer`` takes: the zero convs (first kernels of the backward), the mid block, the down blocks from
+        the deepest level up, conv_in, the condition embedding, and the time embedding last (it collects from every ResnetBlock)."""
+        return controlnet_bucket_ranges([(k, o, _numel(shp)) for k, o, shp in self.layout])
+
+    def step(self, unet_trainer: "LoRATrainer", noisy_latents, timesteps, encoder_hidden_states, target, controlnet_cond,
+             lr: Optional[float] = None):
+        """One whole training step of the ControlNet configuration: recorded ControlNet forward, the UNet step with its residuals
+        (frozen UNet, or LoRA trained alongside: then ``unet_trainer``'s own gradients are filled too and the caller steps it),
+        ControlNet backward, all-reduce of the 1.45 GB bucket, clip + AdamW, in-place re-pack.  Returns the loss."""
+        self.zero_grad()
+        down, mid = self.forward(noisy_latents, timesteps, encoder_hidden_states, controlnet_cond)
+        dg = ([torch.zeros_like(d) for d in down], torch.zeros_like(mid))
+        loss = unet_trainer.forward_backward(noisy_latents, timesteps, encoder_hidden_states, target, down_block_additional_residuals=down,
+                                             mid_block_additional_residual=mid, residual_grads=dg)
+        self.backward(*dg)
+        world = self.all_reduce_grads()
+        self.optimizer_step(world, lr)
+        return loss
 
     def optimizer_step(self, world: int = 1, lr: Optional[float] = None, sumsq: Optional[torch.Tensor] = None):
         """clip + AdamW on the flat vectors, then the new values are re-packed into the handle (forward and dgrad weight copies)."""

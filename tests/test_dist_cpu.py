@@ -287,3 +287,38 @@ def test_bench_self_launches_its_ranks_without_torchrun():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"],
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_controlnet_bucket_ranges_tile_the_flat_vector_in_backward_order():
+    """The 1.45 GB ControlNet gradient bucket of SURVEY.md 8e, cut for `BucketedReducer`: the ranges follow the order in which the
+    backward finalises them (zero convs, mid block, down blocks 3..0, conv_in, condition embedding, time embedding) and tile the flat
+    vector exactly; at SD-1.5 size the total is 361,279,120 parameters.  (Layout = sorted state-dict keys: what the library uses.)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "mri-diffusion-superresolution_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mrisr import dist as md
+    from mrisr import params as P
+    from mrisr.train import controlnet_bucket_ranges
+    import mrisr
+    shapes = {k: tuple(shp) for k, shp, _ in P.controlnet_param_shapes(mrisr.UNetConfig())}   # SD-1.5 size, names only: no GPU needed
+    off, lay = 0, []
+    for k in sorted(shapes):
+        n = 1
+        for d in shapes[k]:
+            n *= d
+        lay.append((k, off, n))
+        off += n
+    ranges = controlnet_bucket_ranges(lay)
+    names = [g for g, _, _ in ranges]
+    assert names[:2] == ["zero_convs", "mid_block"] and names[-3:] == ["conv_in", "controlnet_cond_embedding", "time_embedding"]
+    assert [g for g in names if g.startswith("down_blocks.")] == sorted((g for g in names if g.startswith("down_blocks.")), reverse=True)
+    covered = sorted((lo, hi) for _, lo, hi in ranges)
+    assert covered[0][0] == 0 and covered[-1][1] == off and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert off == 361_279_120   # SURVEY.md App. A: the ControlNet's parameter count
+    # the reducer accepts exactly these buckets (identity without a process group); 1.45 GB of f32: an empty strided stand-in
+    r = md.BucketedReducer(torch.zeros(off, dtype=torch.float32), [(lo, hi) for _, lo, hi in ranges])
+    for i in range(len(ranges)):
+        r.reduce(i)
+    assert r.wait() == 1

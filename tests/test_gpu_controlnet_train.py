@@ -97,3 +97,88 @@ def test_controlnet_weight_gradients_match_autograd(tiny, dt, tol):
             d2, m2 = ou.controlnet_forward(new, cfg, x, t, ctx, cond)
         o2, om2 = cnet(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda(), controlnet_cond=cond.cuda(), return_dict=False)
         assert rel(om2, m2) < 1e-3 and max(rel(a, b) for a, b in zip(o2, d2)) < 1e-3
+
+
+def test_controlnet_whole_step_and_bucket_ranges(tiny):
+    """`ControlNetTrainer.step` (forward, UNet step, backward, exchange, clip + AdamW, re-pack) moves the parameters like the same step
+    done with torch autograd + torch.optim.AdamW on the oracle, twice in a row (the second step runs on the RE-PACKED weights); the
+    bucket ranges tile the gradient vector; and LoRA on the UNet can be trained alongside."""
+    import mrisr
+    from oracle import unet as ou
+    cfg, up, cp = tiny
+    B, h = 2, 8
+    unet = mrisr.UNet2DConditionModel(cfg, compute_dtype="f32")
+    unet.load_state_dict(up)
+    cnet = mrisr.ControlNetModel(cfg, compute_dtype="f32")
+    cnet.load_state_dict(cp)
+    utr = mrisr.LoRATrainer(unet)
+    ctr = mrisr.ControlNetTrainer(cnet, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
+    rng = ctr.bucket_ranges()
+    cov = sorted((lo, hi) for _, lo, hi in rng)
+    assert cov[0][0] == 0 and cov[-1][1] == ctr.num_trainable and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+    cpg = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
+    opt = torch.optim.AdamW(list(cpg.values()), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    for step in range(2):
+        x, t, ctx, tgt, cond = _batch(cfg, B, h, 730 + step)
+        tgt = 30.0 * tgt  # large loss: the clip is active
+        with torch.enable_grad():
+            down, mid = ou.controlnet_forward(cpg, cfg, x, t, ctx, cond)
+            loss_ref = torch.nn.functional.mse_loss(ou.unet_forward(up, cfg, x, t, ctx, down, mid), tgt)
+            opt.zero_grad()
+            loss_ref.backward()
+        norm_ref = float(torch.nn.utils.clip_grad_norm_(list(cpg.values()), 1.0))
+        opt.step()
+        loss = ctr.step(utr, x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), cond.cuda())
+        assert abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-3, step
+        assert norm_ref > 1.0 and abs(ctr.grad_norm() - norm_ref) / norm_ref < 1e-3, (step, ctr.grad_norm(), norm_ref)
+        sd = ctr.state_dict()
+        worst = max((rel(sd[k], cpg[k]), k) for k in cp)
+        assert worst[0] < 1e-3, (step, worst)
+
+
+def test_controlnet_gradients_at_sd15_width():
+    """One step at FULL SD-1.5 width (361,279,120 ControlNet parameters + the frozen 859.5 M UNet; B = 1, 4 x 32 x 32 latents, 256^2-px
+    condition): a tensor of every kind against autograd - condition embedding (first, 3-channel layer and a stride-2 one), conv_in,
+    convs at 320 / 1280 channels, a downsampler, attention projections (fused QKV sections, context K), the GEGLU projection, norm
+    affines, the time-embedding MLP and a per-block projection, zero convs."""
+    import mrisr
+    from oracle import unet as ou
+    cfg = ou.SD15
+    up = ou.init_unet_params(cfg, seed=741, perturb_norm=True)
+    cp = ou.init_controlnet_params(cfg, seed=742, perturb_norm=True)
+    assert sum(v.numel() for v in cp.values()) == 361_279_120
+    g = torch.Generator().manual_seed(743)
+    B, h = 1, 32
+    x, tgt = torch.randn((B, 4, h, h), generator=g), torch.randn((B, 4, h, h), generator=g)
+    ctx = torch.randn((B, 77, 768), generator=g)
+    cond = torch.randn((B, 3, 8 * h, 8 * h), generator=g)
+    t = torch.tensor([417])
+    check = ["controlnet_cond_embedding.conv_in.weight", "controlnet_cond_embedding.blocks.1.weight", "controlnet_cond_embedding.conv_out.bias",
+             "conv_in.weight", "down_blocks.0.resnets.0.conv1.weight", "down_blocks.0.resnets.1.norm2.weight", "down_blocks.0.downsamplers.0.conv.weight",
+             "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_k.weight", "down_blocks.1.attentions.1.transformer_blocks.0.attn2.to_k.weight",
+             "down_blocks.1.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "down_blocks.2.attentions.0.transformer_blocks.0.norm2.bias",
+             "down_blocks.2.resnets.0.conv_shortcut.weight", "down_blocks.3.resnets.1.conv2.weight", "down_blocks.3.resnets.0.time_emb_proj.weight",
+             "mid_block.attentions.0.proj_out.weight", "time_embedding.linear_1.weight", "time_embedding.linear_2.bias",
+             "controlnet_down_blocks.4.weight", "controlnet_mid_block.bias"]
+    cpg = {k: (v.clone().requires_grad_(True) if k in check else v) for k, v in cp.items()}
+    with torch.enable_grad():
+        down, mid = ou.controlnet_forward(cpg, cfg, x, t, ctx, cond)
+        loss_ref = torch.nn.functional.mse_loss(ou.unet_forward(up, cfg, x, t, ctx, down, mid), tgt)
+        loss_ref.backward()
+    unet = mrisr.UNet2DConditionModel(mrisr.UNetConfig(), compute_dtype="f32")
+    unet.load_state_dict(up)
+    cnet = mrisr.ControlNetModel(mrisr.UNetConfig(), compute_dtype="f32")
+    cnet.load_state_dict(cp)
+    utr, ctr = mrisr.LoRATrainer(unet), mrisr.ControlNetTrainer(cnet)
+    assert ctr.num_trainable == 361_279_120 and not ctr.frozen
+    dd, dm = ctr.forward(x.cuda(), t.cuda(), ctx.cuda(), cond.cuda())
+    dg = ([torch.zeros_like(d) for d in dd], torch.zeros_like(dm))
+    loss = utr.forward_backward(x.cuda(), t.cuda(), ctx.cuda(), tgt.cuda(), down_block_additional_residuals=dd, mid_block_additional_residual=dm,
+                                residual_grads=dg)
+    assert abs(float(loss) - float(loss_ref.detach())) / float(loss_ref.detach()) < 1e-3
+    ctr.backward(*dg)
+    gr = ctr.gradients()
+    errs = {k: rel(gr[k], cpg[k].grad) for k in check}
+    for k, e in errs.items():
+        print(f"SD-1.5 ControlNet gradient {k}: rel {e:.3e}")
+    assert max(errs.values()) < 1e-3, errs

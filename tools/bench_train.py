@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--train-adapter", action="store_true", help="BASELINE config 3 in full: Adapter_XL(sk=True, cin=192) on [B,3,256,256] "
                                                                   "runs AND trains every step (233.7 M more parameters, 935 MB gradient bucket)")
     ap.add_argument("--profile", action="store_true", help="per-kernel-class HIP-event profile of one step")
+    ap.add_argument("--train-controlnet", action="store_true", help="the ControlNet configuration: a full ControlNet (361,279,120 trainable parameters) feeding a "
+                                                                     "FROZEN UNet; condition images 8x the latent size; all-reduce of the 1.45 GB bucket")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] training leg: forward through the fp8 projections + fp8 attention "
                                                        "(fp8_train), backward in bf16")
     args = ap.parse_args()
@@ -70,7 +72,11 @@ def main():
     sd = P.random_state_dict(P.unet_param_shapes(cfg), 20260501, dev)  # same weights on every rank
     sd.update(P.random_state_dict(P.lora_param_shapes(cfg, 4), 20260504, dev))
     f8 = dict(fp8=True, fp8_attention=True, fp8_train=True) if args.fp8 else {}
-    unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype, lora_rank=4, lora_alpha=4, lora_fused=True, **f8)
+    if args.train_controlnet:
+        sd = P.random_state_dict(P.unet_param_shapes(cfg), 20260501, dev)
+        unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype)
+    else:
+        unet = mrisr.UNet2DConditionModel(cfg, compute_dtype=args.dtype, lora_rank=4, lora_alpha=4, lora_fused=True, **f8)
     unet.load_state_dict(sd)
     tr = mrisr.LoRATrainer(unet, lr=1e-4)
     B, h = args.batch, args.latent
@@ -92,7 +98,17 @@ def main():
         cond = torch.randn((B, 3, 8 * h, 8 * h), generator=g, device=dev)
         intra = None
 
+    ctr = None
+    if args.train_controlnet:
+        cnet = mrisr.ControlNetModel(cfg, compute_dtype=args.dtype)
+        cnet.load_state_dict(P.random_state_dict(P.controlnet_param_shapes(cfg), 20260507, dev))
+        ctr = mrisr.ControlNetTrainer(cnet, lr=1e-5)
+        assert ctr.num_trainable == 361_279_120, ctr.num_trainable
+        cond = torch.randn((B, 3, 8 * h, 8 * h), generator=g, device=dev)
+
     def one_step():
+        if ctr is not None:
+            return ctr.step(tr, x, t, ctx, noise, cond)
         if atr is not None:
             return mrisr.joint_step(tr, atr, x, t, ctx, noise, cond)
         return tr.step(x, t, ctx, noise, intra)
@@ -121,7 +137,7 @@ def main():
            "dtype": args.dtype + (" (fp8 e4m3 forward: K=320 projections + attention; bf16 backward)" if args.fp8 else ""), "data": "synthetic", "losses": [round(v, 5) for v in losses],
            "workspace_GiB": round(unet.workspace_bytes / 2**30, 2),
            "config": {"workload": f"SD-1.5 UNet + LoRA r=4 fine-tune step, [{B},4,{h},{h}] per GPU, all-reduce of "
-                                  f"{tr.num_trainable} f32 grads" + (f" + trainable Adapter_XL ({atr.num_trainable} f32 grads)" if atr else ""),
+                                  f"{tr.num_trainable} f32 grads" + (f" + trainable Adapter_XL ({atr.num_trainable} f32 grads)" if atr else "") + (f"; TRAINABLE ControlNet ({ctr.num_trainable} f32 grads), UNet frozen" if ctr else ""),
                       "adapter_features": bool(intra), "adapter_trained": atr is not None}}
     if args.profile and rank == 0:
         lib = L.lib()

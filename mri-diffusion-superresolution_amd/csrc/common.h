@@ -169,6 +169,24 @@ struct MlpArgs {
 bool mlp_fused_ok(int C, int H, int N2);
 int launch_pack_mlp_w2(const void* w2_bf16, void* dst, int N2, int H, hipStream_t st);
 int launch_mlp_fused(const MlpArgs& m, hipStream_t st);
+// the row-local middle of a transformer block at C = 320 in one kernel (xtail.hip): attn1.to_out + residual, LayerNorm2, attn2.to_q,
+// cross-attention over the cached prompt K / V, attn2.to_out + residual
+struct XTailArgs {
+    const void* ao = nullptr; int ldao = 0;   // self-attention output rows [M][320]
+    void* t = nullptr; int ldt = 0;           // residual stream rows [M][320]: read as x0, overwritten with x2
+    int M = 0, ntok = 0;                      // rows; tokens per image
+    const void* w1 = nullptr; const float* b1 = nullptr; const void* a1 = nullptr; const float* lb1 = nullptr;  // attn1.to_out: W [320][320] (natural K), LoRA A [r][320], B f32 [320][4]
+    const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-5f;
+    const void* wq = nullptr; const float* bq = nullptr; const void* aq = nullptr; const float* lbq = nullptr;  // attn2.to_q: W K-permuted (launch_pack_mlp_w2)
+    const void* kvp = nullptr; int nk = 0; float scale = 1.f;                                                  // launch_pack_xattn_kv image; keys; 1 / sqrt(d)
+    const void* w2 = nullptr; const float* b2 = nullptr; const void* a2 = nullptr; const float* lb2 = nullptr;  // attn2.to_out: W K-permuted
+    int lora_r = 0;                           // 4 (all three projections carry a rank-4 adapter) or 0
+};
+bool xattn_tail_enabled();
+bool xattn_tail_ok(int C, int heads, int M, int ntok, int nk);
+size_t xattn_tail_kv_bytes(int B);
+int launch_pack_xattn_kv(const void* kc, const void* vtc, void* dst, int B, int ctx_pad, int dpad, int nk, hipStream_t st);
+int launch_xattn_tail(const XTailArgs& x, hipStream_t st);
 int gemm_rp_tile(const GemmArgs& g);  // row-panel kernel id for this (plain, short-K, bf16) GEMM, 0 if it is not eligible
 int gemm_choose(GemmArgs& g, bool is_bf16);  // sets g.tile / g.splitk (autotuned per signature for bf16)  // set launch attributes of every GEMM instantiation (call before graph capture)
 

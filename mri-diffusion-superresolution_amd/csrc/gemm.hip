@@ -3119,6 +3119,7 @@ extern "C" void mrisr_debug_force_split(int s) { g_force_split = s; }
 static int g_gemm_flags = [] { const char* e = getenv("MRISR_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
 extern "C" void mrisr_debug_gemm_flags(int f) { g_gemm_flags = f; }
 static int gemm_flags_now() { return g_gemm_flags; }
+int xattn_tail_flags() { return g_gemm_flags; }
 // tools/table_search.py: overrides one entry of the tile table in this process (key as in the table file)
 extern "C" void mrisr_debug_set_tuned(const char* key, int tile, int split) { g_tuned[key] = {tile, split}; }
 int g_subpix_override = -1;

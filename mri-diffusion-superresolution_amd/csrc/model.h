@@ -18,6 +18,11 @@ struct XfW {
     void* ff2p = nullptr;  // ff2.w with K permuted for the fused feed-forward kernel (bf16, C = 320 only)
     void* kc = nullptr;   // cached cross-attention K   [B*H][ctx_pad][dpad]
     void* vtc = nullptr;  // cached cross-attention V^T [B*H][dpad][ctx_pad]
+    // fused row-local middle of the block (xtail.hip; bf16, C = 320): attn2.to_q / attn2.to_out weights with K permuted to the
+    // accumulator order, and the prompt K / V as per-(image, head pair) LDS images (planned with kc / vtc, packed by set_context)
+    void* q2p = nullptr;
+    void* out2p = nullptr;
+    void* kvp = nullptr;
 };
 struct Level {
     std::vector<ResW> res;

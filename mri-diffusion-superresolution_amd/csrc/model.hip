@@ -263,6 +263,14 @@ struct Packer {
             if (!x.ff2p) { err = 4; return x; }
             if (launch_pack_mlp_w2(x.ff2.w, x.ff2p, x.ff2.n, x.ff2.k, st)) err = 5;
         }
+        // fused middle (xtail.hip xattn_tail_kernel): to_q / to_out of attn2 read their row operand in accumulator order
+        if (sizeof(T) == 2 && !err && x.C == 320 && m.cfg.num_heads == 8 && x.q2.n == 320 && x.q2.k == 320 && x.out2.n == 320 && x.out2.k == 320 &&
+            x.out1.n == 320 && x.out1.k == 320 && !m.cfg.fp8_linears) {
+            x.q2p = m.new_packed((size_t)320 * 320 * sizeof(T), false);
+            x.out2p = m.new_packed((size_t)320 * 320 * sizeof(T), false);
+            if (!x.q2p || !x.out2p) { err = 4; return x; }
+            if (launch_pack_mlp_w2(x.q2.w, x.q2p, 320, 320, st) || launch_pack_mlp_w2(x.out2.w, x.out2p, 320, 320, st)) err = 5;
+        }
         return x;
     }
 };
@@ -477,6 +485,7 @@ static int plan_t(Model& m, int B, int h, int w, int L, hipStream_t st) {
         const HeadBuf& hb = m.head_buf_for_C(x->C);
         const size_t kb = (size_t)B * hb.H * m.ctx_pad * hb.dpad * sizeof(T);
         xoffs.push_back(carve(kb)); xoffs.push_back(carve(kb));
+        xoffs.push_back(x->q2p ? carve(xattn_tail_kv_bytes(B)) : (size_t)0);
     }
     const size_t ctx_off = carve((size_t)B * L * c.cross_attention_dim * sizeof(T));
     m.cond_emb_bytes = (size_t)B * h * w * c.block_out_channels[0] * sizeof(T);
@@ -490,8 +499,9 @@ static int plan_t(Model& m, int B, int h, int w, int L, hipStream_t st) {
         m.heads[i].vt = base + offs[3 * i + 2];
     }
     for (size_t i = 0; i < xfs.size(); ++i) {
-        xfs[i]->kc = base + xoffs[2 * i];
-        xfs[i]->vtc = base + xoffs[2 * i + 1];
+        xfs[i]->kc = base + xoffs[3 * i];
+        xfs[i]->vtc = base + xoffs[3 * i + 1];
+        xfs[i]->kvp = xfs[i]->q2p ? base + xoffs[3 * i + 2] : nullptr;
     }
     m.ctx_rows = base + ctx_off;
     m.cond_emb = base + cond_off;

@@ -303,8 +303,24 @@ struct Runner {
     int project_context(XfW& x, const HeadBuf& hb) {
         GemmArgs g;
         heads_args(&g, hb, x.kc, 0, x.vtc, 1, nullptr, 0, m.ctx_len, m.ctx_pad);
-        return linear(m.ctx_rows, m.ws_B * m.ctx_len, m.cfg.cross_attention_dim, x.kv2, ACT_NONE, nullptr, 0, &g,
-                      nullptr, 0);
+        TRY(linear(m.ctx_rows, m.ws_B * m.ctx_len, m.cfg.cross_attention_dim, x.kv2, ACT_NONE, nullptr, 0, &g,
+                   nullptr, 0));
+        // the same K / V once more as the LDS images of the fused middle (xtail.hip); cheap, so packed whether or not that path is on
+        if (x.kvp && !dry && m.ctx_len <= 80 && hb.hd == 40 && sizeof(T) == 2)
+            TRY(launch_pack_xattn_kv(x.kc, x.vtc, x.kvp, m.ws_B, m.ctx_pad, hb.dpad, m.ctx_len, st));
+        return 0;
+    }
+
+    // attn1.to_out + residual, LayerNorm2, attn2.to_q, cross-attention, attn2.to_out + residual as ONE launch (xtail.hip) when the
+    // block has the geometry that kernel is written for; false: the four launches below
+    bool fused_middle(const XfW& xw, const HeadBuf& hb, int M) const {
+        if (sizeof(T) != 2 || m.keep || !xw.q2p || !xw.kvp || !xattn_tail_enabled() || m.cfg.fp8_attention || !m.cfg.flash_attention) return false;
+        if (!xattn_tail_ok(xw.C, hb.H, M, hb.N, m.ctx_len) || hb.hd != 40) return false;
+        const int R = xw.out1.R;
+        if (xw.q2.R != R || xw.out2.R != R) return false;
+        if (R && !(R == 4 && xw.out1.r == 4 && xw.q2.r == 4 && xw.out2.r == 4 && lora_in_kernel())) return false;
+        if (xw.out1.w8 || xw.q2.w8 || xw.out2.w8) return false;
+        return true;
     }
 
     // ---- Transformer2DModel with one BasicTransformerBlock (App. A.4) ----
@@ -328,6 +344,17 @@ struct Runner {
             TRY(linear(t, M, C, xw.qkv, ACT_NONE, nullptr, 0, &g, nullptr, 0, nullptr, &xw.ln1, nrm));
         }
         TRY(attention(hb, hb.k, hb.vt, hb.N, hb.npad, ao));
+        if (fused_middle(xw, hb, M)) {
+            XTailArgs a;
+            a.ao = ao; a.ldao = C; a.t = t; a.ldt = C; a.M = M; a.ntok = hb.N;
+            a.w1 = xw.out1.w; a.b1 = xw.out1.b; a.a1 = xw.out1.loraA; a.lb1 = xw.out1.loraB;
+            a.ln_g = xw.ln2.g; a.ln_b = xw.ln2.b; a.ln_eps = 1e-5f;
+            a.wq = xw.q2p; a.bq = xw.q2.b; a.aq = xw.q2.loraA; a.lbq = xw.q2.loraB;
+            a.kvp = xw.kvp; a.nk = m.ctx_len; a.scale = 1.0f / sqrtf((float)hb.hd);
+            a.w2 = xw.out2p; a.b2 = xw.out2.b; a.a2 = xw.out2.loraA; a.lb2 = xw.out2.loraB;
+            a.lora_r = xw.out1.R ? 4 : 0;
+            if (!dry) TRY(launch_xattn_tail(a, st));
+        } else {
         TRY(linear(ao, M, C, xw.out1, ACT_NONE, t, C, nullptr, t, C));
         // cross-attention (K/V cached by set_context)
         {
@@ -337,6 +364,7 @@ struct Runner {
         }
         TRY(attention(hb, xw.kc, xw.vtc, m.ctx_len, m.ctx_pad, ao));
         TRY(linear(ao, M, C, xw.out2, ACT_NONE, t, C, nullptr, t, C));
+        }
         // GEGLU feed-forward
         if (xw.ff2p && !m.keep && mlp_fused_ok(C, 4 * C, C)) {
             MlpArgs a;

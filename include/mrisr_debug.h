@@ -47,6 +47,9 @@ void mrisr_debug_subpix(int min_rows);
 /* the fused row-local middle of the C = 320 transformer blocks (csrc/xtail.hip: attn1.to_out + residual, LayerNorm2, attn2.to_q,
  * cross-attention, attn2.to_out + residual in one launch): -1 default (MRISR_XTAIL, on), 0 the four separate launches, 1 on */
 void mrisr_debug_xattn_tail(int on);
+/* probe: device buffer of (workgroups x 40) u64 that every launch of that kernel fills with clock stamps at its phase boundaries
+ * (tools/probes/xtail_stamps.py); NULL (default) = off */
+void mrisr_debug_xattn_tail_stamps(void* dev_buf);
 
 /* micro-benchmark of the fused feed-forward kernel (tools/mlp_probe.py): M rows of width 320, random operands */
 int mrisr_bench_mlp(int M, int hidden, int iters, float* ms_out);

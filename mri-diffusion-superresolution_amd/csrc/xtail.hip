@@ -46,6 +46,12 @@ static __device__ __forceinline__ void xt_dma16(__amdgpu_buffer_rsrc_t r, char* 
 #define XT_OOB 0x80000000u
 typedef __attribute__((ext_vector_type(4))) unsigned xt_u4;
 
+#ifndef XT_PF
+#define XT_PF 2
+#endif
+#ifndef XT_INTERLEAVE
+#define XT_INTERLEAVE 1
+#endif
 constexpr int XT_KVP_PAIR = 40960;     // bytes of one (image, head pair) K / V image
 constexpr int XT_KVP_HEAD = 19456;     // K part 80 keys x 64 slots (10,240 B) + V part 48 columns x 96 slots (9,216 B)
 constexpr int XT_KVP_KPART = 10240;
@@ -61,6 +67,9 @@ struct XTailDev {
     const void* w2; const float* b2; const void* a2; const float* lb2;   // attn2.to_out: W K-permuted
     int lora_r;  // 4 or 0 (all three projections alike)
     int poison;
+    unsigned long long* stamps;  // probe: per workgroup 40 clock stamps (s_memtime) at the phase boundaries, wave 0
+    int rot;     // per-workgroup rotation of the piece order inside a chunk
+    int dbg;     // probe builds of the timing (MRISR_XTAIL_DBG; results are garbage): 1 no weight / K-V DMA after chunk 0, 2 no attention math, 4 no GEMM K loops
 };
 
 template <bool LORA>
@@ -73,6 +82,15 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
     const int fr = lane & 15, fg = lane >> 4;
     const int m0 = blockIdx.x * 128;
     const int img = m0 / a.ntok;
+    int stamp_k = 0;
+    auto stamp = [&]() {
+        if (a.stamps) {
+            if (tid == 0) a.stamps[(size_t)blockIdx.x * 40 + stamp_k] = __builtin_readcyclecounter();
+            ++stamp_k;
+        }
+    };
+    auto substamp = [&](int k) { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 40 + k] = __builtin_readcyclecounter(); };
+    stamp();
     if (a.poison) {
         const unsigned bytes = ((const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_dispatch_ptr())[7];
         for (unsigned o = threadIdx.x * 16u; o + 16u <= bytes; o += 256u * 16u) *reinterpret_cast<uint4*>(smem + o) = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -85,21 +103,44 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
     const __amdgpu_buffer_rsrc_t rkv = xt_rsrc(a.kvp, a.kvp_bytes);
 
     // ---- DMA geometry of a weight chunk: LDS position L (16-byte units) = row * 40 + (c ^ (row & 7)) ----
+    // Every workgroup streams the SAME chunk at about the same time; walked in the same order by all 32 CUs of an XCD the requests
+    // pile up on one L2 channel after the other.  Each workgroup therefore walks the 40 pieces of a chunk in its own rotation
+    // (piece = 4 q + w with q rotated by the workgroup id / 4 and w by the workgroup id): MRISR_XTAIL_ROT=0 turns it off.
     unsigned wvo[10];
+    int ldo[10];
+    const int rot_w = a.rot ? (int)(blockIdx.x & 3) : 0, rot_q = a.rot ? (int)((blockIdx.x >> 2) % 10) : 0;
 #pragma unroll
     for (int p = 0; p < 10; ++p) {
-        const int L = (p * 4 + wave) * 64 + lane;
+        int q = p + rot_q;
+        if (q >= 10) q -= 10;
+        const int piece = q * 4 + ((wave + rot_w) & 3);
+        const int L = piece * 64 + lane;
         const int row = L / CPR, cs = L - row * CPR;
         wvo[p] = (unsigned)(row * (K * 2) + (cs ^ (row & 7)) * 16);
+        ldo[p] = __builtin_amdgcn_readfirstlane(piece * 1024);
     }
     auto stage_w = [&](const __amdgpu_buffer_rsrc_t& rw, int c, int buf) {
+        if (a.dbg & 1) return;
 #pragma unroll
-        for (int p = 0; p < 10; ++p) xt_dma16(rw, smem + buf * CH + (p * 4 + wave) * 1024, wvo[p], (unsigned)c * (unsigned)CH);
+        for (int p = 0; p < 10; ++p) xt_dma16(rw, smem + buf * CH + ldo[p], wvo[p], (unsigned)c * (unsigned)CH);
     };
     auto stage_kv = [&](int pair, int buf) {  // a ready-made LDS image: linear copy
         const unsigned base = (unsigned)(img * 4 + pair) * (unsigned)XT_KVP_PAIR;
+        if (a.dbg & 1) return;
 #pragma unroll
-        for (int p = 0; p < 10; ++p) xt_dma16(rkv, smem + buf * CH + (p * 4 + wave) * 1024, (unsigned)((p * 4 + wave) * 1024 + lane * 16), base);
+        for (int p = 0; p < 10; ++p) xt_dma16(rkv, smem + buf * CH + ldo[p], (unsigned)(ldo[p] + lane * 16), base);
+    };
+    // The NEXT chunk is not staged in one go at the top of a chunk: clock stamps showed the ten DMA instructions of a wave taking ~2,100
+    // cycles to ISSUE (every CU of an XCD pulls the same 40 KB through the same L2 at the same moment: 1.3 MB per chunk step against
+    // ~1 KB / clk of L2 hit bandwidth), during which the wave issues nothing else - as long as the whole K loop (1,950 cycles).  One piece
+    // per K step instead: the MFMAs of the previous step run while the wave sits in the VMEM queue.
+    struct Next { __amdgpu_buffer_rsrc_t r; unsigned soff; int kv; int live; int buf; };
+    auto next_w = [&](const __amdgpu_buffer_rsrc_t& rw, int c, int buf) { return Next{rw, (unsigned)c * (unsigned)CH, 0, 1, buf}; };
+    auto next_kv = [&](int pair, int buf) { return Next{rkv, (unsigned)(img * 4 + pair) * (unsigned)XT_KVP_PAIR, 1, 1, buf}; };
+    auto issue_piece = [&](const Next& nx, int p) {
+        if (!nx.live || (a.dbg & 1)) return;
+        const unsigned vo = nx.kv ? (unsigned)(ldo[p] + lane * 16) : wvo[p];
+        xt_dma16(nx.r, smem + nx.buf * CH + ldo[p], vo, nx.soff);
     };
     // chunk stream: 0-4 to_out(attn1), 5-9 to_q, 10-13 K / V head pairs, 14-18 to_out(attn2)
     auto stage = [&](int cid, int buf) {
@@ -164,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();  // every wave has its rows in registers (and every wave's LoRA / LayerNorm pieces have landed)
     }
+    stamp();  // 1: rows resident
     stage(0, 0);
 
     // ---- building blocks ----
@@ -202,28 +244,54 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
             zf[j] = bf16x8{(bf16)zacc[j][0], (bf16)zacc[j][1], (bf16)zacc[j][2], (bf16)zacc[j][3], (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
     };
     // one 64-column chunk: acc = bias + x W^T (+ z B^T)
-    auto gemm_chunk = [&](int buf, const bf16x8 (&x)[MF][KS], const float (&pb)[NF][4], const f32x4 (&lb)[NF], const bf16x8 (&zf)[MF], f32x4 (&acc)[NF][MF]) {
+    auto gemm_chunk = [&](int buf, const bf16x8 (&x)[MF][KS], const float (&pb)[NF][4], const f32x4 (&lb)[NF], const bf16x8 (&zf)[MF], f32x4 (&acc)[NF][MF],
+                          auto&& per_step, const bool probe = false) {
         const char* sw = smem + buf * CH + fr * (K * 2);
-        bf16x8 wf[2][NF];
+        if (a.dbg & 4) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) per_step(kk);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]};
+            return;
+        }
+        // weight fragments software-pipelined XT_PF K steps ahead: with one wave per SIMD nothing else hides the ds_read latency, and one
+        // K step of 8 MFMAs (128 cycles) is shorter than it (clock stamps: 4,400 cycles per chunk at depth 1 = 31 % of the MFMA time)
+        constexpr int PF = XT_PF;
+        bf16x8 wf[PF + 1][NF];
         auto load_w = [&](bf16x8 (&dst)[NF], int kk) {
             const int off = ((kk * 4 + fg) ^ (fr & 7)) * 16;
 #pragma unroll
             for (int i = 0; i < NF; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(sw + i * 16 * (K * 2) + off);
         };
-        load_w(wf[0], 0);
+#pragma unroll
+        for (int kk = 0; kk < PF; ++kk) load_w(wf[kk], kk);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
+            if (probe && (kk == 0 || kk == 5)) substamp(kk == 0 ? 33 : 34);
+            per_step(kk);
             __builtin_amdgcn_sched_barrier(0);
+            if (kk + PF < KS) load_w(wf[(kk + PF) % (PF + 1)], kk + PF);
 #pragma unroll
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < MF; ++j) {
                     const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc[i][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], x[j][kk], cz, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk % (PF + 1)][i], x[j][kk], cz, 0, 0, 0);
                 }
+            // the four fragment reads of step kk + PF between the MFMA pairs of step kk: a read's issue (the four waves share the LDS
+            // array) then hides behind a running MFMA instead of holding up the first one (clock stamps: 196 -> cycles per K step)
+            if (XT_INTERLEAVE && kk + PF < KS) {
+#pragma unroll
+                for (int q = 0; q < NF; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (probe) substamp(35);
         if (LORA) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
@@ -239,13 +307,38 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
         __syncthreads();                                   // ... for every wave; every wave has left the previous chunk's buffer
     };
 
+    // The chunk loops below are REAL loops (not unrolled): fully unrolled the kernel is ~100 KB of straight-line code that every wave
+    // executes once - it ran at the instruction-fetch rate (90 us per launch, 12 % of the MFMA time).  Register arrays cannot be indexed by
+    // the loop counter, so the row arrays ROTATE instead: every iteration consumes the front two K steps / appends its two new K steps at
+    // the back (64 v_mov per chunk), and after five iterations the array is in natural order again.
+    auto rotate2 = [&](bf16x8 (&x)[MF][KS], const bf16x8 (&nw)[MF][2]) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+#pragma unroll
+            for (int kk = 0; kk + 2 < KS; ++kk) x[j][kk] = x[j][kk + 2];
+            x[j][KS - 2] = nw[j][0];
+            x[j][KS - 1] = nw[j][1];
+        }
+    };
+    auto swap_halves = [&](bf16x8 (&x)[MF][KS]) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+#pragma unroll
+            for (int kk = 0; kk < KS / 2; ++kk) { const bf16x8 tmp = x[j][kk]; x[j][kk] = x[j][kk + KS / 2]; x[j][kk + KS / 2] = tmp; }
+    };
+    const bf16x8 zero8 = bf16x8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+
     // =========================== GEMM 1: x1 = to_out(ao) + x0 ===========================
     bf16x8 zf[MF];
     if (LORA) lora_z(smem + LA_OFF, af, false, zf);
     prefetch_cols(a.b1, a.lb1, 0);
+    stamp();  // 2: z of the first projection
     bf16x8 x1f[MF][KS];  // x1 (bf16) in the permuted operand layout = accumulator layout of fragment pairs
-    float s1[MF] = {0.f, 0.f}, s2[MF] = {0.f, 0.f}, c0[MF] = {0.f, 0.f};
 #pragma unroll
+    for (int j = 0; j < MF; ++j)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) x1f[j][kk] = zero8;
+#pragma nounroll
     for (int c = 0; c < 5; ++c) {
         const int buf = c & 1;
         chunk_top();
@@ -257,32 +350,32 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
             for (int r = 0; r < 4; ++r) pb[i][r] = pbn[i][r];
             if (LORA) lb[i] = lbn[i];
         }
-        stage(c + 1, buf ^ 1);
         bf16x4 rvn[NF][MF];
-        if (c + 1 < 5) { load_resid(c + 1, rvn); prefetch_cols(a.b1, a.lb1, c + 1); }
-        else prefetch_cols(a.bq, a.lbq, 0);
+        const Next nx = c + 1 < 5 ? next_w(rw1, c + 1, buf ^ 1) : next_w(rwq, 0, buf ^ 1);
         f32x4 acc[NF][MF];
-        gemm_chunk(buf, af, pb, lb, zf, acc);
+        gemm_chunk(buf, af, pb, lb, zf, acc, [&](int kk) {
+            issue_piece(nx, kk);
+            if (kk == 1) {
+                load_resid(min(c + 1, 4), rvn);
+                if (c + 1 < 5) prefetch_cols(a.b1, a.lb1, c + 1); else prefetch_cols(a.bq, a.lbq, 0);
+            }
+        });
+        bf16x8 nw[MF][2];
 #pragma unroll
         for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int j = 0; j < MF; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bf16 v = (bf16)acc[i][j][r];                                 // the projection's bf16 output ...
-                    const bf16 x = (bf16)((float)v + (float)rv[i][j][r]);              // ... plus the residual, rounded again (as the unfused epilogue)
-                    x1f[j][2 * c + (i >> 1)][(i & 1) * 4 + r] = x;
-                    if (c == 0 && i == 0 && r == 0) c0[j] = __shfl((float)x, fr);      // the row's element 0 (held by the lane with fg = 0)
-                    const float d = (float)x - c0[j];
-                    s1[j] += d;
-                    s2[j] = fmaf(d, d, s2[j]);
+                    const bf16 v = (bf16)acc[i][j][r];                                  // the projection's bf16 output ...
+                    nw[j][i >> 1][(i & 1) * 4 + r] = (bf16)((float)v + (float)rv[i][j][r]);  // ... plus the residual, rounded again (as the unfused epilogue)
                 }
-        if (c + 1 < 5) {
+        rotate2(x1f, nw);
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
-                for (int j = 0; j < MF; ++j) rv[i][j] = rvn[i][j];
-        }
+            for (int j = 0; j < MF; ++j) rv[i][j] = rvn[i][j];
+        stamp();  // 3-7
     }
     // =========================== LayerNorm 2 on the resident x1 ===========================
     bf16x8 xn[MF][KS];
@@ -290,12 +383,17 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
         float mean[MF], rstd[MF];
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
-            float t1 = s1[j], t2 = s2[j];
-            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
-            const float md = t1 * (1.0f / K);
-            mean[j] = c0[j] + md;
-            rstd[j] = rsqrtf(fmaxf(t2 * (1.0f / K) - md * md, 0.f) + a.ln_eps);
+            const float c0 = __shfl((float)x1f[j][0][0], fr);  // the row's element 0 (slot 0 of K step 0 in the lane with fg = 0)
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)x1f[j][kk][e] - c0; s1 += d; s2 = fmaf(d, d, s2); }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const float md = s1 * (1.0f / K);
+            mean[j] = c0 + md;
+            rstd[j] = rsqrtf(fmaxf(s2 * (1.0f / K) - md * md, 0.f) + a.ln_eps);
         }
         const float* gp = reinterpret_cast<const float*>(smem + GB_OFF) + fg * 4;
         const float* bp = reinterpret_cast<const float*>(smem + GB_OFF + 2048) + fg * 4;
@@ -316,12 +414,22 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
         }
     }
     // =========================== GEMM 2: q = to_q(LayerNorm2(x1)) ===========================
+    stamp();  // 8: LayerNorm
     if (LORA) lora_z(smem + LA_OFF + LA_SZ, xn, true, zf);
+    stamp();  // 9
     bf16x8 qf[MF][KS];
 #pragma unroll
+    for (int j = 0; j < MF; ++j)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) qf[j][kk] = zero8;
+#pragma nounroll
     for (int c = 0; c < 5; ++c) {
-        const int cid = 5 + c, buf = cid & 1;
-        chunk_top();
+        const int buf = (c + 1) & 1;  // chunk id 5 + c
+        if (c == 2) substamp(25);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c == 2) substamp(26);
+        __syncthreads();
+        if (c == 2) substamp(27);
         float pb[NF][4];
         f32x4 lb[NF];
 #pragma unroll
@@ -330,133 +438,163 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
             for (int r = 0; r < 4; ++r) pb[i][r] = pbn[i][r];
             if (LORA) lb[i] = lbn[i];
         }
-        stage(cid + 1, buf ^ 1);
-        if (c + 1 < 5) prefetch_cols(a.bq, a.lbq, c + 1);
+        const Next nx = c + 1 < 5 ? next_w(rwq, c + 1, buf ^ 1) : next_kv(0, buf ^ 1);
+        if (c == 2) substamp(28);
         f32x4 acc[NF][MF];
-        gemm_chunk(buf, xn, pb, lb, zf, acc);
+        gemm_chunk(buf, xn, pb, lb, zf, acc, [&](int kk) {
+            issue_piece(nx, kk);
+            if (kk == 1 && c + 1 < 5) prefetch_cols(a.bq, a.lbq, c + 1);
+        });
+        if (c == 2) substamp(29);
+        bf16x8 nw[MF][2];
 #pragma unroll
         for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int j = 0; j < MF; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qf[j][2 * c + (i >> 1)][(i & 1) * 4 + r] = (bf16)acc[i][j][r];
+                for (int r = 0; r < 4; ++r) nw[j][i >> 1][(i & 1) * 4 + r] = (bf16)acc[i][j][r];
+        rotate2(qf, nw);
+        stamp();  // 10-14
     }
     // =========================== cross-attention over the cached prompt K / V ===========================
+    // Heads come in groups of four = 160 columns = five K steps, after which the column pattern repeats: the loop body handles one group
+    // (two K / V chunks) with static indices into the FRONT halves of q and o, and the halves are swapped after each group.
     bf16x8 of[MF][KS];
 #pragma unroll
     for (int j = 0; j < MF; ++j)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) of[j][kk] = bf16x8{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-    f32x4 carry[MF];
+        for (int kk = 0; kk < KS; ++kk) of[j][kk] = zero8;
+#pragma nounroll
+    for (int grp = 0; grp < 2; ++grp) {
+        f32x4 carry[MF];
 #pragma unroll
-    for (int j = 0; j < MF; ++j) carry[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MF; ++j) carry[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int cid = 10 + p, buf = cid & 1;
-        chunk_top();
-        stage(cid + 1, buf ^ 1);
-        if (p == 3) prefetch_cols(a.b2, a.lb2, 0);
+        for (int pp = 0; pp < 2; ++pp) {
+            const int buf = pp;  // chunk id 10 + 2 grp + pp
+            chunk_top();
+            const Next nx = pp == 0 ? next_kv(2 * grp + 1, buf ^ 1) : (grp == 0 ? next_kv(2, buf ^ 1) : next_w(rw2, 0, buf ^ 1));
+            if (pp == 1 && grp == 1) prefetch_cols(a.b2, a.lb2, 0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int h = 2 * p + s;
-            const int kk0 = (40 * h) / 32;
-            const char* hb = smem + buf * CH + s * XT_KVP_HEAD;
-            // S = Q K^T: 5 key fragments x 2 K steps
-            f32x4 sacc[5][MF];
-            {
-                const char* kb = hb + fr * 128;
+            for (int s = 0; s < 2; ++s) {
+                if (a.dbg & 2) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    bf16x8 kf[5];
+                    for (int q = 0; q < 5; ++q) issue_piece(nx, s * 5 + q);
+                    continue;
+                }
+                const int hl = 2 * pp + s;          // head inside the group: columns 40 hl .. 40 hl + 39 of the group's 160
+                const int kk0 = (40 * hl) / 32;     // 0, 1, 2, 3
+                const char* hb = smem + buf * CH + s * XT_KVP_HEAD;
+                // S = Q K^T: 5 key fragments x 2 K steps
+                f32x4 sacc[5][MF];
+                {
+                    const char* kb = hb + fr * 128;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) kf[i] = *reinterpret_cast<const bf16x8*>(kb + i * 16 * 128 + (((t * 4 + fg) ^ (fr & 7)) * 16));
+                    for (int t = 0; t < 2; ++t) {
+                        issue_piece(nx, s * 5 + t);
+                        bf16x8 kf[5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) kf[i] = *reinterpret_cast<const bf16x8*>(kb + i * 16 * 128 + (((t * 4 + fg) ^ (fr & 7)) * 16));
+#pragma unroll
+                        for (int i = 0; i < 5; ++i)
+#pragma unroll
+                            for (int j = 0; j < MF; ++j) {
+                                const f32x4 cz = t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[i][j];
+                                sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[j][kk0 + t], cz, 0, 0, 0);
+                            }
+                    }
+                }
+                // softmax over the keys of each row (a row's keys: 5 fragments x 4 registers in each of the 4 lanes {fr + 16 fg'})
+                bf16x8 pk[3][MF];
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    // raw scores: max first (the scale is positive), then exp2(s * sl2 - max * sl2) as one FMA + v_exp per key; only the
+                    // last key fragment can hold keys >= nk when nk > 64 (the K image is zero there: a finite score, masked here)
+                    float mx = -INFINITY;
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
 #pragma unroll
-                        for (int j = 0; j < MF; ++j) {
-                            const f32x4 cz = t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[i][j];
-                            sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[j][kk0 + t], cz, 0, 0, 0);
+                        for (int r = 0; r < 4; ++r) {
+                            if (i == 4 || a.nk <= 64) { if (i * 16 + fg * 4 + r >= a.nk) sacc[i][j][r] = -INFINITY; }
+                            mx = fmaxf(mx, sacc[i][j][r]);
+                        }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float nm = -mx * a.sl2;
+                    float l = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(sacc[i][j][r], a.sl2, nm));
+                            sacc[i][j][r] = e;
+                            l += e;
+                        }
+                    l += __shfl_xor(l, 16);
+                    l += __shfl_xor(l, 32);
+                    const float inv = 1.0f / l;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int i = 2 * t + (e >> 2);
+                            pk[t][j][e] = i < 5 ? (bf16)(sacc[i < 5 ? i : 0][j][e & 3] * inv) : (bf16)0.f;
                         }
                 }
-            }
-            // softmax over the keys of each row (a row's keys: 5 fragments x 4 registers in each of the 4 lanes {fr + 16 fg'})
-            bf16x8 pk[3][MF];
+                // O = P V: the 3 column blocks the head touches x 3 K steps of keys
+                f32x4 oacc[3][MF];
 #pragma unroll
-            for (int j = 0; j < MF; ++j) {
-                float mx = -INFINITY;
+                for (int b = 0; b < 3; ++b)
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < MF; ++j) oacc[b][j] = (s == 1 && b == 0) ? carry[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                {
+                    const char* vb = hb + XT_KVP_KPART + fr * 192;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = sacc[i][j][r] * a.sl2;
-                        if (i * 16 + fg * 4 + r >= a.nk) v = -INFINITY;
-                        sacc[i][j][r] = v;
-                        mx = fmaxf(mx, v);
+                    for (int t = 0; t < 3; ++t) {
+                        issue_piece(nx, s * 5 + 2 + t);
+                        bf16x8 vf[3];
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) vf[b] = *reinterpret_cast<const bf16x8*>(vb + b * 16 * 192 + (((t * 4 + fg) ^ ((fr >> 2) & 3)) * 16));
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)
+#pragma unroll
+                            for (int j = 0; j < MF; ++j) oacc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[b], pk[t][j], oacc[b][j], 0, 0, 0);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float l = 0.f;
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(sacc[i][j][r] - mx);
-                        sacc[i][j][r] = e;
-                        l += e;
-                    }
-                l += __shfl_xor(l, 16);
-                l += __shfl_xor(l, 32);
-                const float inv = 1.0f / l;
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int i = 2 * t + (e >> 2);
-                        pk[t][j][e] = i < 5 ? (bf16)(sacc[i < 5 ? i : 0][j][e & 3] * inv) : (bf16)0.f;
-                    }
-            }
-            // O = P V: the 3 column blocks the head touches x 3 K steps of keys
-            f32x4 oacc[3][MF];
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-#pragma unroll
-                for (int j = 0; j < MF; ++j) oacc[b][j] = (s == 1 && b == 0) ? carry[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            {
-                const char* vb = hb + XT_KVP_KPART + fr * 192;
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    bf16x8 vf[3];
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) vf[b] = *reinterpret_cast<const bf16x8*>(vb + b * 16 * 192 + (((t * 4 + fg) ^ ((fr >> 2) & 3)) * 16));
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-#pragma unroll
-                        for (int j = 0; j < MF; ++j) oacc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[b], pk[t][j], oacc[b][j], 0, 0, 0);
                 }
-            }
-            // finished blocks -> the row operand of the last GEMM; the block an even head shares with the next head is carried
-            const int gb0 = (40 * h) / 16;
+                // finished blocks -> the row operand of the last GEMM; the block an even head shares with the next head is carried
+                const int gb0 = (40 * hl) / 16;     // 0, 2, 5, 7 inside the group's ten blocks
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                if (s == 0 && b == 2) {
+                for (int b = 0; b < 3; ++b) {
+                    if (s == 0 && b == 2) {
 #pragma unroll
-                    for (int j = 0; j < MF; ++j) carry[j] = oacc[b][j];
-                } else {
-                    const int gb = gb0 + b;
+                        for (int j = 0; j < MF; ++j) carry[j] = oacc[b][j];
+                    } else {
+                        const int gb = gb0 + b;
 #pragma unroll
-                    for (int j = 0; j < MF; ++j)
+                        for (int j = 0; j < MF; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) of[j][gb >> 1][(gb & 1) * 4 + r] = (bf16)oacc[b][j][r];
+                            for (int r = 0; r < 4; ++r) of[j][gb >> 1][(gb & 1) * 4 + r] = (bf16)oacc[b][j][r];
+                    }
                 }
             }
         }
+        swap_halves(qf);
+        swap_halves(of);
+        stamp();  // 15-16
     }
     // =========================== GEMM 3: x2 = to_out(o) + x1 ===========================
     if (LORA) lora_z(smem + LA_OFF + 2 * LA_SZ, of, true, zf);
-#pragma unroll
+    stamp();  // 17
+#pragma nounroll
     for (int c = 0; c < 5; ++c) {
-        const int cid = 14 + c, buf = cid & 1;
-        chunk_top();
+        const int buf = c & 1;  // chunk id 14 + c
+        if (c == 4) substamp(30);
+        // the eight x2 stores of the previous chunk are the youngest VMEM operations of this wave and may stay in flight (vmcnt retires in
+        // order: everything older - this chunk's DMA pieces, the bias / LoRA loads - has landed once at most eight are outstanding)
+        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+        if (c == 4) substamp(31);
         float pb[NF][4];
         f32x4 lb[NF];
 #pragma unroll
@@ -465,9 +603,15 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
             for (int r = 0; r < 4; ++r) pb[i][r] = pbn[i][r];
             if (LORA) lb[i] = lbn[i];
         }
-        if (c + 1 < 5) { stage(cid + 1, buf ^ 1); prefetch_cols(a.b2, a.lb2, c + 1); }
+        Next nx = next_w(rw2, min(c + 1, 4), buf ^ 1);
+        nx.live = c + 1 < 5;
         f32x4 acc[NF][MF];
-        gemm_chunk(buf, of, pb, lb, zf, acc);
+        gemm_chunk(buf, of, pb, lb, zf, acc, [&](int kk) {
+            issue_piece(nx, kk);
+            if (kk == 1 && c + 1 < 5) prefetch_cols(a.b2, a.lb2, c + 1);
+        }, c == 4);
+        if (c == 4) substamp(32);
+        bf16x8 nw[MF][2];
 #pragma unroll
         for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -475,31 +619,29 @@ __global__ __launch_bounds__(256, 1) void xattn_tail_kernel(const XTailDev a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bf16 v = (bf16)acc[i][j][r];
-                    const int kk = 2 * c + (i >> 1), e = (i & 1) * 4 + r;
-                    x1f[j][kk][e] = (bf16)((float)v + (float)x1f[j][kk][e]);
+                    nw[j][i >> 1][(i & 1) * 4 + r] = (bf16)((float)v + (float)x1f[j][i >> 1][(i & 1) * 4 + r]);  // the front two K steps: this chunk's x1
                 }
-    }
-    // ---- x2 (now in x1f) -> wave-private row tile (natural column order) -> whole rows ----
-    __syncthreads();  // every wave is done with the ring and the LoRA rows: the tiles overlay them
-    constexpr int OP = K + 8;
-    bf16* wt = reinterpret_cast<bf16*>(smem + wave * (32 * OP * 2));
+        // x2 leaves chunk by chunk, straight from the accumulator layout (8 bytes per lane; the four fg lanes x four fragments of a row
+        // fill one 128-byte line within this chunk, L2 merges them): the write is spread over the GEMM instead of one 21 MB burst of
+        // all workgroups at the end (clock stamps: staging + whole-row stores took as long as three chunks)
+        {
+            bf16* ob = reinterpret_cast<bf16*>(a.t);
 #pragma unroll
-    for (int j = 0; j < MF; ++j)
+            for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 v = x1f[j][kk];
-            *reinterpret_cast<bf16x4*>(wt + (j * 16 + fr) * OP + kk * 32 + fg * 4) = bf16x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<bf16x4*>(wt + (j * 16 + fr) * OP + kk * 32 + 16 + fg * 4) = bf16x4{v[4], v[5], v[6], v[7]};
+                for (int j = 0; j < MF; ++j) {
+                    const int m = m0 + wave * 32 + j * 16 + fr;
+                    const bf16x8 v = nw[j][i >> 1];
+                    const bf16x4 o = (i & 1) ? bf16x4{v[4], v[5], v[6], v[7]} : bf16x4{v[0], v[1], v[2], v[3]};
+                    if (m < a.M) *reinterpret_cast<bf16x4*>(ob + (size_t)m * a.ldt + c * 64 + i * 16 + fg * 4) = o;
+                }
         }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes
-    bf16* ob = reinterpret_cast<bf16*>(a.t);
-#pragma unroll
-    for (int it = 0; it < 32 * CPR / 64; ++it) {
-        const int idx = it * 64 + lane;
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int m = m0 + wave * 32 + row;
-        if (m < a.M) *reinterpret_cast<bf16x8*>(ob + (size_t)m * a.ldt + ch * 8) = *reinterpret_cast<const bf16x8*>(wt + row * OP + ch * 8);
+        rotate2(x1f, nw);
+        stamp();  // 18-22
     }
+    stamp();  // 23: stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();  // 24: stores done
 }
 
 // K [B*8][ctx_pad][dpad] and V^T [B*8][dpad][ctx_pad] of the prompt (bf16, head-major, as the attention kernel reads them) ->
@@ -559,6 +701,8 @@ int launch_pack_xattn_kv(const void* kc, const void* vtc, void* dst, int B, int 
     return 0;
 }
 
+static unsigned long long* g_xt_stamps = nullptr;
+extern "C" void mrisr_debug_xattn_tail_stamps(void* dev_buf) { g_xt_stamps = static_cast<unsigned long long*>(dev_buf); }
 static int g_xtail = -1;  // test hook: -1 = MRISR_XTAIL (default 1), 0 off, 1 on
 extern "C" void mrisr_debug_xattn_tail(int on) { g_xtail = on; }
 bool xattn_tail_enabled() {
@@ -594,6 +738,11 @@ int launch_xattn_tail(const XTailArgs& x, hipStream_t st) {
     d.w2 = x.w2; d.b2 = x.b2 ? x.b2 : zp; d.a2 = x.a2; d.lb2 = x.lb2;
     d.lora_r = x.lora_r;
     d.poison = (xattn_tail_flags() & 2048) ? 1 : 0;
+    static const int dbg = [] { const char* e = getenv("MRISR_XTAIL_DBG"); return e ? atoi(e) : 0; }();
+    d.dbg = dbg;
+    static const int rot = [] { const char* e = getenv("MRISR_XTAIL_ROT"); return e ? atoi(e) : 1; }();
+    d.rot = rot;
+    d.stamps = g_xt_stamps;
     const double fl = 2.0 * x.M * (3.0 * 320 * 320 + 2.0 * 320 * x.nk) + (x.lora_r ? 2.0 * x.M * 3 * 2 * 320 * 4 : 0.0);
     const double by = 2.0 * x.M * 320 * 3 + 3.0 * 320 * 320 * 2;
     ProfScope ps("xattn_tail_c320", fl, by, st);

@@ -1680,20 +1680,38 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
     // ---- weight chunk DMA geometry: LDS position L (16-byte units) = row * CPR + (c ^ swz(row)) ----
     static_assert(PIECES % NW == 0, "every wave issues the same number of DMA pieces (no control flow around them: the compiler's\n"
                                    "wait-count model turns conditional VMEM issue into vmcnt(0) drains)");
+    // All workgroups of the grid stream the same weight chunks at about the same time; walked in the same order by the 32 CUs of an XCD
+    // the requests pile up on one L2 channel after the other (clock stamps in xtail.hip: a wave's ten DMA instructions took 2,100 cycles
+    // to issue, 1,500 with the rotation).  g.dbg & 4096 turns the rotation off (MRISR_RP_ROT=0).
     unsigned wvo[PPW];
+    int ldo[PPW];
+    const bool rot = !(g.dbg & 4096);
+    const int rot_w = rot ? (int)(blockIdx.x % NW) : 0, rot_q = rot ? (int)((blockIdx.x / NW + blockIdx.y) % PPW) : 0;
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
-        const int L = (p * NW + wave) * 64 + lane;
+        int q = p + rot_q;
+        if (q >= PPW) q -= PPW;
+        const int piece = q * NW + (wave + rot_w) % NW;
+        const int L = piece * 64 + lane;
         const int row = L / CPR, cs = L - row * CPR;
         const int c = cs ^ swz(row);
         wvo[p] = (unsigned)(row * K * EW + c * 16);
+        ldo[p] = __builtin_amdgcn_readfirstlane(piece * 1024);
     }
     // `live` false: the chunk does not exist - every lane's offset lies beyond num_records, the DMA writes zeros (harmless)
     auto stage_w = [&](int chunk, int buf, bool live) {
         char* sb = smem + buf * CHUNK;
         const unsigned base = live ? (unsigned)chunk * (unsigned)CHUNK : 0xC0000000u;  // rows past N also lie beyond num_records
 #pragma unroll
-        for (int p = 0; p < PPW; ++p) bl16(rw, sb + (p * NW + wave) * 1024, wvo[p], base);
+        for (int p = 0; p < PPW; ++p) bl16(rw, sb + ldo[p], wvo[p], base);
+    };
+    // the same, the pieces of K step kk only (default; g.dbg & 8192 = all at the top of the chunk as before): the next chunk's DMA spread over this chunk's K loop - the wave waits in the VMEM queue behind running MFMAs (bench step 9.80 -> 9.72 ms)
+    const bool spread = !(g.dbg & 8192);
+    auto stage_step = [&](int chunk, int buf, bool live, int kk) {
+        char* sb = smem + buf * CHUNK;
+        const unsigned base = live ? (unsigned)chunk * (unsigned)CHUNK : 0xC0000000u;
+#pragma unroll
+        for (int p = kk * PPW / KS; p < (kk + 1) * PPW / KS; ++p) bl16(rw, sb + ldo[p], wvo[p], base);
     };
 
     // ---- the panel rows: registers, MFMA second-operand layout (row = fr of fragment j, k = 32 kk + 8 fg ..) ----
@@ -1922,7 +1940,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
         else if (young == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // chunk c has landed; every wave has left chunk c - 1 (its buffer, incl. the staging regions, is free)
-        stage_w(c + 1, buf ^ 1, c + 1 < c_end);  // unconditional issue (see stage_w): the K loop's bias wait stays a counted one
+        if (!spread) stage_w(c + 1, buf ^ 1, c + 1 < c_end);  // unconditional issue (see stage_w): the K loop's bias wait stays a counted one
         bf16x8 lbf[NF];
         if (LORA) {
 #pragma unroll
@@ -1949,6 +1967,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
             load_w(wf[0], 0);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
+                if (spread) { stage_step(c + 1, buf ^ 1, c + 1 < c_end, kk); __builtin_amdgcn_sched_barrier(0); }
                 if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
                 if (RP_READS_FIRST) __builtin_amdgcn_sched_barrier(0);  // else the scheduler sinks the prefetch to the end of the step
 #pragma unroll
@@ -1977,6 +1996,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
             load_w(wf[0], 0);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
+                if (spread) { stage_step(c + 1, buf ^ 1, c + 1 < c_end, kk); __builtin_amdgcn_sched_barrier(0); }
                 if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
                 if (RP_READS_FIRST) __builtin_amdgcn_sched_barrier(0);  // else the scheduler sinks the prefetch to the end of the step
 #pragma unroll
@@ -2119,6 +2139,8 @@ struct MlpDev {
     const void* resid; int ldr;
     void* out; int ldo; int H;
     int poison;  // test hook: lds_poison before the first DMA
+    int rot;     // per-workgroup rotation of the piece order inside a chunk (MRISR_MLP_ROT, default 1)
+    int spread;  // next chunk's DMA one piece per K step instead of all at the top of the chunk (MRISR_MLP_SPREAD, default 1)
 };
 
 template <int KS, int DBG>
@@ -2142,29 +2164,45 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
 
     // DMA geometry.  W1 chunk: as in the row-panel kernel (row pitch K*2, 16-byte chunk c ^ (row & 7)).  W2 chunk: rows of 64 B
     // (4 chunks), chunk q ^ g((row & 15) >> 2) with g = {0, 2, 3, 1}: conflict-free ds_read_b128 of 16 rows x one chunk
+    // Every workgroup streams the same chunk at about the same time: each walks the pieces of a chunk in its own rotation, so that the
+    // CUs of an XCD do not pile up on one L2 channel after the other (a.rot; clock stamps in the sister kernel xtail.hip: the ten DMA
+    // instructions of a wave took 2,100 cycles to issue, 1,500 rotated).
     unsigned wvo1[10], wvo2[5];
+    int ldo1[10], ldo2[5];
+    const int rot_w = a.rot ? (int)(blockIdx.x & 3) : 0, rot_q = a.rot ? (int)((blockIdx.x >> 2) % 10) : 0;
 #pragma unroll
     for (int p = 0; p < 10; ++p) {
-        const int L = (p * 4 + wave) * 64 + lane;
+        int q = p + rot_q;
+        if (q >= 10) q -= 10;
+        const int piece = q * 4 + ((wave + rot_w) & 3);
+        const int L = piece * 64 + lane;
         const int row = L / CPR, cs = L - row * CPR;
         wvo1[p] = (unsigned)((row * K + (cs ^ (row & 7)) * 8) * 2);
+        ldo1[p] = __builtin_amdgcn_readfirstlane(piece * 1024);
     }
     auto gsw = [](int x) { return (0x78 >> (2 * x)) & 3; };  // {0, 2, 3, 1}
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
-        const int L = (p * 4 + wave) * 64 + lane;
+        int q = p + (rot_q >> 1);
+        if (q >= 5) q -= 5;
+        const int piece = q * 4 + ((wave + rot_w) & 3);
+        const int L = piece * 64 + lane;
         const int row = L >> 2, qs = L & 3;
-        const int q = qs ^ gsw((row & 15) >> 2);
-        wvo2[p] = (unsigned)(((size_t)row * a.H + q * 8) * 2);
+        const int qq = qs ^ gsw((row & 15) >> 2);
+        wvo2[p] = (unsigned)(((size_t)row * a.H + qq * 8) * 2);
+        ldo2[p] = __builtin_amdgcn_readfirstlane(piece * 1024);
     }
     auto stage = [&](int c, int buf, bool live) {
         const unsigned b1o = live ? (unsigned)c * (unsigned)CH1 : 0xC0000000u;
         const unsigned b2o = live ? (unsigned)c * 64u : 0xC0000000u;
 #pragma unroll
-        for (int p = 0; p < 10; ++p) bl16(r1, smem + buf * CH1 + (p * 4 + wave) * 1024, wvo1[p], b1o);
+        for (int p = 0; p < 10; ++p) bl16(r1, smem + buf * CH1 + ldo1[p], wvo1[p], b1o);
 #pragma unroll
-        for (int p = 0; p < 5; ++p) bl16(r2, smem + W2BASE + buf * CH2 + (p * 4 + wave) * 1024, wvo2[p], b2o);
+        for (int p = 0; p < 5; ++p) bl16(r2, smem + W2BASE + buf * CH2 + ldo2[p], wvo2[p], b2o);
     };
+    // one piece of chunk c at a time (a.spread): the wave waits in the VMEM queue behind a running MFMA instead of ahead of the K loop
+    auto stage1 = [&](int c, int buf, bool live, int p) { bl16(r1, smem + buf * CH1 + ldo1[p], wvo1[p], live ? (unsigned)c * (unsigned)CH1 : 0xC0000000u); };
+    auto stage2 = [&](int c, int buf, bool live, int p) { bl16(r2, smem + W2BASE + buf * CH2 + ldo2[p], wvo2[p], live ? (unsigned)c * 64u : 0xC0000000u); };
 
     // ---- the panel rows through LDS (the W1 buffers are still empty), then LayerNorm in registers ----
     bf16x8 af[MF][KS];
@@ -2264,34 +2302,48 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
         for (int i = 0; i < NF1; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pb[i][r] = pbn[i][r];
-        {
+        const bool live = c + 1 < nchunks && !(DBG & 1);
+        const bool spread = a.spread != 0;
+        auto next_bias = [&]() {
             const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
             for (int i = 0; i < NF1; ++i) load4<float>(a.b1 + cn * 64 + i * 16 + fg * 4, pbn[i]);
-        }
-        stage(c + 1, buf ^ 1, c + 1 < nchunks && !(DBG & 1));
+        };
+        if (!spread) { next_bias(); stage(c + 1, buf ^ 1, live); }
         // ---- FF1 chunk ----
         f32x4 acc1[NF1][MF];
         const char* s1 = smem + buf * CH1 + fr * (K * 2);
-        bf16x8 wf[2][NF1];
+        constexpr int PF = 2;  // fragment reads two K steps ahead (one wave per SIMD: nothing else hides the ds_read latency)
+        bf16x8 wf[PF + 1][NF1];
         auto load_w = [&](bf16x8 (&dst)[NF1], int kk) {
             const int off = ((kk * 4 + fg) ^ (fr & 7)) * 16;
 #pragma unroll
             for (int i = 0; i < NF1; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(s1 + i * 16 * (K * 2) + off);
         };
-        load_w(wf[0], 0);
+#pragma unroll
+        for (int kk = 0; kk < PF; ++kk) load_w(wf[kk], kk);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
-            __builtin_amdgcn_sched_barrier(0);  // the reads first: the scheduler otherwise sinks them to the end of the step
+            if (spread) { stage1(c + 1, buf ^ 1, live, kk); if (kk == 1) next_bias(); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + PF < KS) load_w(wf[(kk + PF) % (PF + 1)], kk + PF);
 #pragma unroll
             for (int i = 0; i < NF1; ++i)
 #pragma unroll
                 for (int j = 0; j < MF; ++j) {
                     const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc1[i][j];
-                    if (DBG & 4) { acc1[i][j] = cz; acc1[i][j][0] += (float)wf[kk & 1][i][0]; continue; }
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], af[j][kk], cz, 0, 0, 0);
+                    if (DBG & 4) { acc1[i][j] = cz; acc1[i][j][0] += (float)wf[kk % (PF + 1)][i][0]; continue; }
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk % (PF + 1)][i], af[j][kk], cz, 0, 0, 0);
                 }
+            // the four fragment reads of step kk + PF between the MFMA pairs of this step: their issue (four waves share the LDS array)
+            // hides behind a running MFMA (xtail.hip clock stamps: 196 -> 177 cycles per K step)
+            if (!(DBG & 4) && kk + PF < KS) {
+#pragma unroll
+                for (int q = 0; q < NF1; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- GEGLU in registers -> FF2's row operand: k elements 0..3 = hidden 4fg + r of block 0, 4..7 = of block 1 ----
@@ -2312,11 +2364,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
 #pragma unroll
         for (int i0 = 0; i0 < NF2; i0 += 4) {
             const int cur = (i0 >> 2) & 1;
+            if (spread) stage2(c + 1, buf ^ 1, live, i0 >> 2);
+            __builtin_amdgcn_sched_barrier(0);
             if (i0 + 4 < NF2) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) w2f[cur ^ 1][u] = *reinterpret_cast<const bf16x8*>(s2 + (i0 + 4 + u) * 16 * 64);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -2324,6 +2377,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
                     if (DBG & 8) { acc2[i0 + u][j][0] += (float)w2f[cur][u][0] + (float)h[j][0]; continue; }
                     acc2[i0 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[cur][u], h[j], acc2[i0 + u][j], 0, 0, 0);
                 }
+            if (!(DBG & 8) && i0 + 4 < NF2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -2414,6 +2474,9 @@ int launch_mlp_fused(const MlpArgs& m, hipStream_t st) {
     d.w2p = m.w2p; d.b2 = m.b2 ? m.b2 : static_cast<const float*>(zero_page());
     d.resid = m.resid; d.ldr = m.ldr; d.out = m.out; d.ldo = m.ldo; d.H = m.H;
     d.poison = (gemm_flags_now() & 2048) ? 1 : 0;
+    static const int rot = [] { const char* e = getenv("MRISR_MLP_ROT"); return e ? atoi(e) : 1; }();
+    static const int spread = [] { const char* e = getenv("MRISR_MLP_SPREAD"); return e ? atoi(e) : 1; }();
+    d.rot = rot; d.spread = spread;
     const double fl = 2.0 * m.M * ((double)2 * m.H * m.C + (double)m.H * m.N2);
     const double by = 2.0 * ((double)m.M * m.C * (m.resid ? 3 : 2) + 3.0 * m.H * m.C);
     ProfScope ps("mlp_fused_c320", fl, by, st);

@@ -44,6 +44,10 @@ void mrisr_debug_sk_inkernel(int on);
  * rows), 0 off (the literal up-sampled conv), n > 0: from n rows on */
 void mrisr_debug_subpix(int min_rows);
 
+/* split-K conv whose only consumer is a GroupNorm: -1 default (MRISR_GN_SLABS, on) the GroupNorm kernel sums the f32 slabs itself
+ * (one launch instead of splitk_reduce + GroupNorm), 0 the two launches, 1 on */
+void mrisr_debug_gn_slabs(int on);
+
 /* the fused row-local middle of the C = 320 transformer blocks (csrc/xtail.hip: attn1.to_out + residual, LayerNorm2, attn2.to_q,
  * cross-attention, attn2.to_out + residual in one launch): -1 default (MRISR_XTAIL, on), 0 the four separate launches, 1 on */
 void mrisr_debug_xattn_tail(int on);

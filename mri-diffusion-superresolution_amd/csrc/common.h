@@ -106,6 +106,7 @@ struct GemmArgs {
     // per-tile arrival counters (zero between launches): the last split of a tile to arrive sums the slabs and runs the kernel's own
     // epilogue, so no separate reduce launch follows (set by launch_gemm for the bf16 DMA kernels; null = splitk_reduce_kernel)
     unsigned* sk_counters = nullptr;
+    int defer_reduce = 0;      // split-K: leave the f32 slabs in `partial`, launch no reduce (the caller's next kernel sums them: launch_groupnorm_slabs)
     int pretouch = 0;  // set by launch_gemm (> 0: pieces per wave at most): the workgroups DMA-touch the whole weight matrix at kernel start (cold weights, see gemm.hip)
     // ---- epilogue ----
     float alpha = 1.0f;
@@ -207,6 +208,22 @@ struct GroupNormArgs {
     int nsplit = 1;
 };
 int groupnorm_nsplit(int B, int HW);
+// The epilogue of a split-K conv / linear whose only consumer is a GroupNorm, done by the GroupNorm kernel itself: it sums the f32 slabs
+// (+ bias, time-embedding row, residual - the operations of splitk_reduce_kernel in the same order), rounds to bf16 as the reduce would
+// have, optionally stores that raw tensor, and normalises from registers.  One launch instead of reduce + GroupNorm.
+struct GnSlabSrc {
+    const float* partial = nullptr;   // [splitk][M][C] f32
+    int splitk = 1;
+    float alpha = 1.f;
+    const float* bias = nullptr;      // [C] or null
+    const float* rowvec = nullptr;    // [(M / rowvec_div)][rowvec_ld] or null
+    int rowvec_ld = 0, rowvec_div = 1;
+    const void* resid = nullptr;      // [M][ldr] bf16 or null
+    int ldr = 0;
+    void* raw_out = nullptr;          // [M][C] bf16 or null: the un-normalised tensor, if anything else reads it
+};
+bool groupnorm_slabs_ok(int C, int groups, int HW);
+int launch_groupnorm_slabs(const GroupNormArgs& a, const GnSlabSrc& s, hipStream_t st);
 // geometry of the one-pass (image slab in registers) GroupNorm kernels, forward and backward; false: two-kernel path
 bool gn_fused_geometry(int c0, int c1, int groups, int HW, int* slab, int* slots, int* rl, int* nv, int ve = 8);
 template <typename T> int launch_groupnorm(const GroupNormArgs& a, hipStream_t st);

@@ -3295,7 +3295,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         const_cast<GemmArgs&>(g).pretouch = (on && sizeof(T) == 2 && g.batch == 1 && (long long)g.N * g.K * 2 >= min_b) ? cap : 0;
     }
     const_cast<GemmArgs&>(g).sk_counters = nullptr;
-    if (g.splitk > 1 && sizeof(T) == 2 && tile_reduces_in_kernel(tile)) {
+    if (g.splitk > 1 && sizeof(T) == 2 && !g.defer_reduce && tile_reduces_in_kernel(tile)) {
         const long long ntiles = tile_count(tile, g) * (long long)g.batch;
         if (ntiles > 0 && ntiles <= kSkCounters) const_cast<GemmArgs&>(g).sk_counters = sk_counters_for(st);
     }
@@ -3322,7 +3322,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         default: rc = launch_cfg<T, 128, 128, 2, 2>(g, st); break;
     }
     if (rc) return rc;
-    if (g.splitk > 1 && !g.sk_counters) return launch_splitk_reduce<T>(g, st);
+    if (g.splitk > 1 && !g.sk_counters && !g.defer_reduce) return launch_splitk_reduce<T>(g, st);
     return 0;
 }
 

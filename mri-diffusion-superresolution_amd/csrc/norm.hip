@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs a, in
 // (split 0; the other splits zero) for the backward pass.  All slabs of an image run on one XCD (4 MB L2 absorbs the
 // partial cache lines of the 80...240-byte slab rows); falls back to the two-kernel path when a slab does not fit.
 // ------------------------------------------------------------------------------------------------
-template <int NVM, int VE>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, int slab, int slots, int RL, int nslab, int xcd_map) {
+template <int NVM, int VE, bool SLAB = false>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, int slab, int slots, int RL, int nslab, int xcd_map, const GnSlabSrc ss = GnSlabSrc()) {
     typedef bf16 T;
     typedef __attribute__((ext_vector_type(VE))) __bf16 vec_t;  // 16-byte (VE = 8) or 8-byte (VE = 4) channel vectors
     __shared__ float part[256 * 16];   // [tid][s1[VE] at 0 | s2[VE] at 8]
@@ -213,10 +213,52 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
 #pragma unroll
     for (int e = 0; e < VE; ++e) s1[e] = s2[e] = 0.f;
     if (active) {
+        if constexpr (SLAB) {
+            // the input does not exist yet: it is the split-K GEMM's output, summed here from the f32 slabs with splitk_reduce_kernel's
+            // operations in its order (sum over splits, * alpha + bias, + time-embedding row, + residual), rounded to bf16 as it would have been
+            typedef __attribute__((ext_vector_type(VE))) float fvec_t;
+            const size_t MN = (size_t)a.B * a.HW * C;
+            fvec_t bv;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) bv[e] = 0.f;
+            if (ss.bias) bv = *reinterpret_cast<const fvec_t*>(ss.bias + ch);
+#pragma unroll
+            for (int i = 0; i < NVM; ++i) {
+                const int r = rl + i * RL;
+                if (r < a.HW) {
+                    const size_t mrow = (size_t)b * a.HW + r;
+                    const float* pp = ss.partial + mrow * C + ch;
+                    fvec_t v;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v[e] = 0.f;
+                    for (int sp = 0; sp < ss.splitk; ++sp) {
+                        const fvec_t t = *reinterpret_cast<const fvec_t*>(pp + (size_t)sp * MN);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) v[e] += t[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v[e] = v[e] * ss.alpha + bv[e];
+                    if (ss.rowvec) {
+                        const fvec_t t = *reinterpret_cast<const fvec_t*>(ss.rowvec + (mrow / ss.rowvec_div) * ss.rowvec_ld + ch);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) v[e] += t[e];
+                    }
+                    if (ss.resid) {
+                        const vec_t t = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(ss.resid) + mrow * ss.ldr + ch);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) v[e] += (float)t[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) xv[i][e] = (bf16)v[e];
+                    if (ss.raw_out) *reinterpret_cast<vec_t*>(reinterpret_cast<T*>(ss.raw_out) + mrow * C + ch) = xv[i];
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NVM; ++i) {
             const int r = rl + i * RL;
             if (r < a.HW) xv[i] = *reinterpret_cast<const vec_t*>(src + (size_t)r * ld);
+        }
         }
 #pragma unroll
         for (int i = 0; i < NVM; ++i) {
@@ -431,6 +473,49 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
         case 3: hipLaunchKernelGGL((gn_apply_kernel<T, 3>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
         default: hipLaunchKernelGGL((gn_apply_kernel<T, 4>), dim3(bx, a.B), dim3(256), 0, st, a, slots, RL, rows_per_block); break;
     }
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int g_gn_slabs = -1;  // test hook: -1 = MRISR_GN_SLABS (default 1), 0 off, 1 on
+extern "C" void mrisr_debug_gn_slabs(int on) { g_gn_slabs = on; }
+static bool gn_slabs_geometry(int C, int groups, int HW, int B, int* ve, int* slab, int* slots, int* rl, int* nv) {
+    if (!gn_fused_geometry(C, 0, groups, HW, slab, slots, rl, nv, 8)) return false;
+    *ve = 8;
+    int s4 = 0, sl4 = 0, rl4 = 0, nv4 = 0;
+    if (B * (C / *slab) < 512 && gn_fused_geometry(C, 0, groups, HW, &s4, &sl4, &rl4, &nv4, 4) && C / s4 > C / *slab) {
+        *ve = 4; *slab = s4; *slots = sl4; *rl = rl4; *nv = nv4;
+    }
+    return *nv <= 8;  // the slabs are summed into registers: few vectors per thread (the deep levels: 8 x 8 and 4 x 4 maps, 16 x 16 at most)
+}
+bool groupnorm_slabs_ok(int C, int groups, int HW) {
+    static const int env = [] { const char* e = getenv("MRISR_GN_SLABS"); return e ? atoi(e) : 1; }();
+    if (g_gn_slabs < 0 ? !env : !g_gn_slabs) return false;
+    if (C % groups || groups > 64 || C % 8) return false;
+    int ve, slab, slots, rl, nv;
+    return gn_slabs_geometry(C, groups, HW, 32, &ve, &slab, &slots, &rl, &nv);
+}
+int launch_groupnorm_slabs(const GroupNormArgs& a, const GnSlabSrc& s, hipStream_t st) {
+    const int C = a.c0;
+    MRISR_REQUIRE(a.c1 == 0 && a.x1 == nullptr && C % a.groups == 0 && a.groups <= 64 && C % 8 == 0, "GroupNorm from slabs: one source, whole groups");
+    MRISR_REQUIRE(s.partial && s.splitk >= 1 && a.partial != nullptr && a.nsplit >= 1 && (!s.rowvec || s.rowvec_div >= 1) && (!s.resid || s.ldr % 8 == 0), "GroupNorm from slabs: operands");
+    int ve, slab, slots, rl, nv;
+    MRISR_REQUIRE(gn_slabs_geometry(C, a.groups, a.HW, a.B, &ve, &slab, &slots, &rl, &nv), "GroupNorm from slabs: geometry (groupnorm_slabs_ok)");
+    const int nslab = C / slab;
+    const int xmap = (a.B % 8) == 0 ? 1 : 0;
+    std::string nf = "groupnorm_from_slabs";
+    if (prof_enabled() && prof_shapes()) {
+        char buf[96];
+        snprintf(buf, sizeof(buf), " B=%d HW=%d C=%d s=%d", a.B, a.HW, C, s.splitk);
+        nf += buf;
+    }
+    const double act_bytes = (double)a.B * a.HW * C * 2.0;
+    ProfScope ps(prof_intern(nf), 0.0, act_bytes * (2.0 * s.splitk + 1.0 + (s.raw_out ? 1.0 : 0.0) + (s.resid ? 1.0 : 0.0)), st);
+    const dim3 fg(a.B * nslab);
+#define GNS_GO(NV, VEV) hipLaunchKernelGGL((gn_fused_kernel<NV, VEV, true>), fg, dim3(256), 0, st, a, slab, slots, rl, nslab, xmap, s)
+    if (ve == 8) { if (nv <= 2) GNS_GO(2, 8); else if (nv <= 4) GNS_GO(4, 8); else GNS_GO(8, 8); }
+    else { if (nv <= 2) GNS_GO(2, 4); else if (nv <= 4) GNS_GO(4, 4); else GNS_GO(8, 4); }
+#undef GNS_GO
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -103,6 +103,54 @@ struct Runner {
         return run_gemm(g);
     }
 
+    // conv3x3 whose only consumer is a GroupNorm (+ SiLU): when the autotuner splits K for it, the f32 slabs are summed by the GroupNorm
+    // kernel itself (launch_groupnorm_slabs: the reduce's operations in its order, then the normalisation from registers) - one launch
+    // instead of splitk_reduce + GroupNorm.  raw (optional): also store the un-normalised output (something else reads it).
+    int conv3_gn(const Act& x, const Act* x1, const ConvW& cw, const float* rowvec, int rowvec_ld, int rowvec_div, const Act* resid,
+                 const NormW& nw, bool silu, float eps, Act* raw, Act* out) {
+        const int Cin = x.C + (x1 ? x1->C : 0);
+        MRISR_REQUIRE(cw.cin == Cin && cw.ks == 3 && nw.c == cw.cout, "conv3x3 + GroupNorm weight mismatch");
+        GemmArgs g;
+        g.a0 = x.p; g.c0 = x.C; g.lda0 = x.C;
+        if (x1) { g.a1 = x1->p; g.c1 = x1->C; g.lda1 = x1->C; }
+        g.conv = 1; g.B = x.B; g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W; g.stride = 1; g.ups = 0;
+        g.w = cw.w; g.M = x.B * x.H * x.W; g.N = cw.cout; g.K = 9 * Cin;
+        g.bias = cw.b; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rowvec_div = rowvec_div; g.act = ACT_NONE;
+        if (resid) { g.resid = resid->p; g.ldr = resid->C; }
+        g.ldo = cw.cout;
+        bool fuse = sizeof(T) == 2 && !m.keep && groupnorm_slabs_ok(cw.cout, m.cfg.norm_num_groups, x.H * x.W);
+        if (fuse) {
+            g.out = reinterpret_cast<void*>(0x1000);  // (never written: the slabs are the output) - the planner only looks at the signature
+            TRY(gemm_choose(g, true));
+            fuse = g.splitk > 1;
+        }
+        if (!fuse) {
+            Act h;
+            TRY(conv3(x, x1, cw, 1, 0, rowvec, rowvec_ld, rowvec_div, resid, ACT_NONE, &h));
+            if (raw) *raw = h;
+            return gn(h, nullptr, nw, silu, eps, out);
+        }
+        Act h;
+        h.B = x.B; h.H = x.H; h.W = x.W; h.C = cw.cout; h.p = nullptr;
+        if (raw) { h = new_act(x.B, x.H, x.W, cw.cout); if (!h.p) return 7; *raw = h; }
+        *out = new_act(x.B, x.H, x.W, cw.cout);
+        if (!out->p) return 7;
+        GroupNormArgs a;
+        a.x0 = nullptr; a.c0 = cw.cout; a.B = x.B; a.HW = x.H * x.W; a.groups = m.cfg.norm_num_groups; a.eps = eps;
+        a.gamma = nw.g; a.beta = nw.b; a.silu = silu ? 1 : 0; a.y = out->p;
+        a.nsplit = groupnorm_nsplit(a.B, a.HW);
+        a.partial = static_cast<float*>(alloc((size_t)a.B * a.nsplit * a.groups * 2 * sizeof(float)));
+        g.partial = static_cast<float*>(alloc((size_t)g.splitk * g.M * g.N * sizeof(float)));
+        if (!a.partial || !g.partial) return 7;
+        if (dry) return 0;
+        g.defer_reduce = 1;
+        TRY(launch_gemm<T>(g, st));
+        GnSlabSrc ss;
+        ss.partial = g.partial; ss.splitk = g.splitk; ss.alpha = g.alpha; ss.bias = g.bias; ss.rowvec = g.rowvec; ss.rowvec_ld = g.rowvec_ld;
+        ss.rowvec_div = g.rowvec_div; ss.resid = g.resid; ss.ldr = g.ldr; ss.raw_out = h.p;
+        return launch_groupnorm_slabs(a, ss, st);
+    }
+
     // Upsample2D: nearest x2, then conv3x3 (diffusers).  Every output pixel (2y + py, 2x + px) reads only a
     // 2 x 2 window of the LOW-resolution input (the three up-sampled rows it touches are two input rows), so the layer is four 2 x 2
     // convs - one per output parity, filter taps pre-summed at load (launch_pack_conv_subpix) - at 4/9 of the MACs: one batched implicit
@@ -214,8 +262,7 @@ struct Runner {
         Act xn, h, hn;
         TRY(gn(x, x1, r.n1, true, m.cfg.norm_eps, &xn));
         const int div = m.t_scalar ? INT_MAX : x.H * x.W;
-        TRY(conv3(xn, nullptr, r.c1, 1, 0, m.tproj_out + r.temb_off, m.tproj_total, div, nullptr, ACT_NONE, &h));
-        TRY(gn(h, nullptr, r.n2, true, m.cfg.norm_eps, &hn));
+        TRY(conv3_gn(xn, nullptr, r.c1, m.tproj_out + r.temb_off, m.tproj_total, div, nullptr, r.n2, true, m.cfg.norm_eps, nullptr, &hn));
         Act res = x;
         if (r.has_sc) {
             // 1x1 shortcut on the (concatenated) raw input, written straight into the output buffer

@@ -422,3 +422,51 @@ def test_sampler_kind_errors():
     with pytest.raises(RuntimeError):  # x0 clipping is a DDPM option
         L = mrisr._lib
         L.check(L.lib().mrisr_sampler_set_clip(mrisr.Sampler(net, sp, kind="ddim")._h, 1.0))
+
+
+@pytest.mark.parametrize("split", [2, 4])
+def test_groupnorm_sums_the_split_k_slabs_itself_and_changes_no_bit(tiny, split):
+    """conv1 -> GroupNorm2 of every resnet: when K is split for the conv, the GroupNorm kernel sums the f32 slabs itself (the reduce
+    kernel's operations in its order: bias, time-embedding row, bf16 rounding) instead of a reduce launch followed by a GroupNorm launch.
+    Same bits as the two launches (mrisr_debug_gn_slabs(0)), per-sample timesteps and a scalar one; the launch counts say which ran."""
+    import ctypes as C
+    import json
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg, up, lora, _ = tiny
+    p = {**up, **lora}
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, cfg.cross_attention_dim), generator=g)
+    lib = L.lib()
+
+    def run(net, t):
+        net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda())
+        lib.mrisr_prof_reset(); lib.mrisr_prof_enable(1)
+        out = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample.clone()
+        torch.cuda.synchronize(); lib.mrisr_prof_enable(0)
+        buf = C.create_string_buffer(1 << 20)
+        n = lib.mrisr_prof_report(buf, len(buf))
+        cls = json.loads(buf.value[:n].decode())
+        lib.mrisr_prof_reset()
+        return out, cls
+    try:
+        lib.mrisr_debug_force_split(C.c_int(split))
+        net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
+        net.load_state_dict(p)
+        for t in (torch.tensor([3, 600]), torch.tensor(77)):
+            lib.mrisr_debug_gn_slabs(C.c_int(0))
+            two, c0 = run(net, t)
+            lib.mrisr_debug_gn_slabs(C.c_int(1))
+            one, c1 = run(net, t)
+            n_fused = c1.get("groupnorm_from_slabs", {}).get("launches", 0)
+            assert "groupnorm_from_slabs" not in c0 and n_fused >= 8, (n_fused, sorted(c1))
+            assert c0["splitk_reduce"]["launches"] - c1["splitk_reduce"]["launches"] == n_fused
+            assert torch.equal(one, two), float((one.float() - two.float()).abs().max())
+        ref = ou.unet_forward(p, cfg, x, torch.tensor([3, 600]), ctx)
+        lib.mrisr_debug_gn_slabs(C.c_int(1))
+        assert rel(net(x.cuda(), torch.tensor([3, 600]).cuda(), encoder_hidden_states=ctx.cuda()).sample, ref) < 5e-2
+    finally:
+        lib.mrisr_debug_force_split(C.c_int(0))
+        lib.mrisr_debug_gn_slabs(C.c_int(-1))

@@ -781,12 +781,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
         cc = k0 - tap * Ct;
     }
 
-    auto stage = [&](int kt, int buf) {
+    // a stage's DMA in two halves (weights + adapter rows | activation rows).  Probe (g.dbg & 16384): the second half issued between the
+    // two K sub-steps of the tile being computed instead of at its top - what helps the one-wave-per-SIMD row-panel kernels (the wave's
+    // time in the VMEM queue overlaps MFMAs already issued) costs this kernel 2.3 % of the whole step (10.10 -> 10.33 ms, same box,
+    // profiles/r03z_bl_ab.log): with two workgroups per CU the other workgroup already fills the stall, and the later issue shortens the
+    // time the tile has to land.  Off.
+    auto stage_w = [&](int kt, int buf) {
         char* sb = smem + buf * STAGE;
         const unsigned k0b = (unsigned)kt * BK * 2;
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) bl16(rw, sb + BM * 128 + (it * 256 + wave * 64) * 16, wvo[it], k0b);
         if (LORA && (wave < 2 || NSTAGE > 2)) bl16(rl, sb + (BM + BN) * 128 + (wave & 1) * 64 * 16, lvo, k0b);
+    };
+    auto stage_a = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE;
+        const unsigned k0b = (unsigned)kt * BK * 2;
         if (!g.conv) {
             const bool second = kt * BK >= g.c0;
             if (!second) {
@@ -826,6 +835,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             if (cc >= Ct) { cc = 0; ++tap; }
         }
     };
+    auto stage = [&](int kt, int buf) { stage_w(kt, buf); stage_a(kt, buf); };
     (void)acb;
 
     f32x4 acc[NF][MF];
@@ -860,11 +870,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
 #pragma unroll
     for (int j = 0; j < MF; ++j) zacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, auto&& mid) {
         const char* sa = smem + buf * STAGE;
         const char* sw = sa + BM * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1) mid();
             const int phys = ((kk * 4 + fg) ^ (fr & 7)) * 16;
             bf16x8 wf[NF], af[MF];
 #pragma unroll
@@ -890,9 +901,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int cur = 0;
+            const bool halves = (g.dbg & 16384) != 0;
             for (int kt = kt_beg; kt < kt_end; ++kt) {
-                if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
-                compute(cur);
+                const bool more = kt + 1 < kt_end;
+                if (more) { if (halves) stage_w(kt + 1, cur ^ 1); else stage(kt + 1, cur ^ 1); }
+                compute(cur, [&]() {
+                    if (halves) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) stage_a(kt + 1, cur ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 cur ^= 1;
@@ -920,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bl_kernel(const GemmArgs g) {  //
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (kt + NSTAGE - 1 < kt_end) stage(kt + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
-            compute(slot);
+            compute(slot, []() {});
             slot = slot + 1 == NSTAGE ? 0 : slot + 1;
         }
         __syncthreads();  // the epilogue reuses the stage buffers

@@ -313,7 +313,8 @@ def main():
                               "it says nothing about image quality",
                    "slices_per_gpu_per_step": B, "ddim_steps": args.ddim_steps, "parallelism": f"slice-sharded x{world} (no collective)",
                    "lora": "merged" if args.lora_merged else "explicit adapters, down-projection + rank-r update inside the projection GEMMs",
-                   "tile_table": os.environ.get("MRISR_TUNE_CACHE", "online autotune"), "hipgraph": not args.no_graph},
+                   "tile_table": (os.path.relpath(os.environ["MRISR_TUNE_CACHE"], ROOT) if os.environ.get("MRISR_TUNE_CACHE") else "online autotune"),
+                   "hipgraph": not args.no_graph},
         "denoise_step_ms": step_ms,
         "unet_tflops_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms,
         "frac_of_bf16_peak_end_to_end": UNET_GFLOP_PER_SAMPLE * B / step_ms / PEAK_BF16_TFLOPS,

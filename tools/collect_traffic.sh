@@ -25,7 +25,8 @@ def cls(name):
     if m: return f"gemm_{'fp8' if m.group(3) in ('1', 'true') else 'bf16'}_rp{int(m.group(1)) * 32}x{int(m.group(2)) * 16}"
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", name)
     if m: return f"gemm_{'bf16' if m.group(1) != 'f' else 'f32'}_{m.group(2)}x{m.group(3)}"
-    if "gn_fused" in name: return "groupnorm_fused"
+    if "xattn_tail" in name: return "xattn_tail_c320"
+    if "gn_fused" in name: return "groupnorm_from_slabs" if re.search(r"gn_fused_kernelILi\d+ELi\d+ELb1E", name) or re.search(r"gn_fused_kernel<\d+, \d+, true>", name) else "groupnorm_fused"
     if "mlp_fused" in name: return "mlp_fused_c320"
     for k, v in (("attn_fwd", "flash_attention"), ("gn_stats", "groupnorm_stats"), ("gn_apply", "groupnorm_apply"), ("layernorm", "layernorm"),
                  ("splitk_reduce", "splitk_reduce"), ("lora_down", "lora_down"), ("small_conv", "small_conv"), ("gemv_rows", "time_embed_gemv")):

@@ -44,6 +44,10 @@ void mrisr_debug_sk_inkernel(int on);
  * rows), 0 off (the literal up-sampled conv), n > 0: from n rows on */
 void mrisr_debug_subpix(int min_rows);
 
+/* the transformer's proj_out + outer residual as a continuation of the fused feed-forward kernel (C = 320): -1 default (MRISR_MLP_PROJ, on),
+ * 0 its own launch, 1 on */
+void mrisr_debug_mlp_proj(int on);
+
 /* split-K conv whose only consumer is a GroupNorm: -1 default (MRISR_GN_SLABS, on) the GroupNorm kernel sums the f32 slabs itself
  * (one launch instead of splitk_reduce + GroupNorm), 0 the two launches, 1 on */
 void mrisr_debug_gn_slabs(int on);

@@ -166,8 +166,13 @@ struct MlpArgs {
     const void* resid = nullptr; int ldr = 0;
     void* out = nullptr; int ldo = 0;
     int C = 0, H = 0, N2 = 0;
+    // optional continuation: out2 = out Wp^T + bp + xres (the transformer's proj_out + outer residual); `out` itself is then not stored
+    const void* wp = nullptr; const float* bp = nullptr;   // [N2][N2] packed by launch_pack_mlp_w2
+    const void* xres = nullptr; int ldxr = 0;
+    void* out2 = nullptr; int ldo2 = 0;
 };
 bool mlp_fused_ok(int C, int H, int N2);
+bool mlp_proj_enabled();  // the transformer's proj_out + outer residual as a continuation of the fused feed-forward kernel (MRISR_MLP_PROJ, default 1)
 int launch_pack_mlp_w2(const void* w2_bf16, void* dst, int N2, int H, hipStream_t st);
 int launch_mlp_fused(const MlpArgs& m, hipStream_t st);
 // the row-local middle of a transformer block at C = 320 in one kernel (xtail.hip): attn1.to_out + residual, LayerNorm2, attn2.to_q,

@@ -2158,11 +2158,15 @@ struct MlpDev {
     const void* resid; int ldr;
     void* out; int ldo; int H;
     int poison;  // test hook: lds_poison before the first DMA
+    // optional continuation (the transformer's proj_out, C = 320 -> 320, no adapter): out2 = (out rows) Wp^T + bp + xres, the FF output never stored
+    const void* wp; const float* bp;   // [320][320] K permuted to the accumulator order; bias (never null when wp is set)
+    const void* xres; int ldxr;        // outer residual rows (the transformer's input), bf16
+    void* out2; int ldo2;
     int rot;     // per-workgroup rotation of the piece order inside a chunk (MRISR_MLP_ROT, default 1)
     int spread;  // next chunk's DMA one piece per K step instead of all at the top of the chunk (MRISR_MLP_SPREAD, default 1)
 };
 
-template <int KS, int DBG>
+template <int KS, int DBG, bool PROJ = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
     typedef bf16 T;
     constexpr int K = KS * 32, N2 = K, MF = 2, NF1 = 4, NF2 = N2 / 16;
@@ -2222,6 +2226,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
     // one piece of chunk c at a time (a.spread): the wave waits in the VMEM queue behind a running MFMA instead of ahead of the K loop
     auto stage1 = [&](int c, int buf, bool live, int p) { bl16(r1, smem + buf * CH1 + ldo1[p], wvo1[p], live ? (unsigned)c * (unsigned)CH1 : 0xC0000000u); };
     auto stage2 = [&](int c, int buf, bool live, int p) { bl16(r2, smem + W2BASE + buf * CH2 + ldo2[p], wvo2[p], live ? (unsigned)c * 64u : 0xC0000000u); };
+    constexpr bool proj = PROJ;
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(proj ? a.wp : a.w1, proj ? (unsigned)(N2 * K * 2) : 0u);
+    auto stageP = [&](int q, int buf, int p) { bl16(rP, smem + buf * CH1 + ldo1[p], wvo1[p], (unsigned)q * (unsigned)CH1); };
 
     // ---- the panel rows through LDS (the W1 buffers are still empty), then LayerNorm in registers ----
     bf16x8 af[MF][KS];
@@ -2328,7 +2335,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
 #pragma unroll
             for (int i = 0; i < NF1; ++i) load4<float>(a.b1 + cn * 64 + i * 16 + fg * 4, pbn[i]);
         };
-        if (!spread) { next_bias(); stage(c + 1, buf ^ 1, live); }
+        if (!spread) {
+            next_bias();
+            stage(c + 1, buf ^ 1, live);
+            if (proj && c + 1 == nchunks) {
+#pragma unroll
+                for (int p = 0; p < 10; ++p) stageP(0, buf ^ 1, p);
+            }
+        }
         // ---- FF1 chunk ----
         f32x4 acc1[NF1][MF];
         const char* s1 = smem + buf * CH1 + fr * (K * 2);
@@ -2343,7 +2357,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
         for (int kk = 0; kk < PF; ++kk) load_w(wf[kk], kk);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (spread) { stage1(c + 1, buf ^ 1, live, kk); if (kk == 1) next_bias(); }
+            if (spread) {
+                if (proj && c + 1 == nchunks) stageP(0, buf ^ 1, kk); else stage1(c + 1, buf ^ 1, live, kk);
+                if (kk == 1) next_bias();
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (kk + PF < KS) load_w(wf[(kk + PF) % (PF + 1)], kk + PF);
 #pragma unroll
@@ -2407,6 +2424,113 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
         }
     }
 
+    if constexpr (PROJ) {
+        // ---- continuation: t2 = bf16(bf16(acc2) + resid) becomes the row operand (accumulator order = the K permutation Wp is packed with) of
+        // one more GEMM, 5 chunks of 64 output columns through the W1 ring; its output (+ bias + outer residual) leaves chunk by chunk straight
+        // from the accumulator layout.  The FF output itself is never stored: 21 MB less written and read back, one launch less.
+        const T* rb = reinterpret_cast<const T*>(a.resid);
+        bf16x8 t2[MF][KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = min(m0 + wave * 32 + j * 16 + fr, a.M - 1);
+                bf16x4 r0 = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, r1v = r0;
+                if (rb) {
+                    r0 = *reinterpret_cast<const bf16x4*>(rb + (size_t)m * a.ldr + kk * 32 + fg * 4);
+                    r1v = *reinterpret_cast<const bf16x4*>(rb + (size_t)m * a.ldr + kk * 32 + 16 + fg * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bf16 v = (bf16)acc2[2 * kk + (e >> 2)][j][e & 3];
+                    t2[j][kk][e] = (bf16)((float)v + (float)(e < 4 ? r0[e & 3] : r1v[e & 3]));
+                }
+            }
+        const T* xr = reinterpret_cast<const T*>(a.xres);
+        T* ob2 = reinterpret_cast<T*>(a.out2);
+        bf16x4 xv[NF1][MF], xvn[NF1][MF];
+        auto load_x = [&](int q, bf16x4 (&dst)[NF1][MF]) {
+#pragma unroll
+            for (int i = 0; i < NF1; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = min(m0 + wave * 32 + j * 16 + fr, a.M - 1);
+                    dst[i][j] = *reinterpret_cast<const bf16x4*>(xr + (size_t)m * a.ldxr + q * 64 + i * 16 + fg * 4);
+                }
+        };
+        float pbp[NF1][4], pbpn[NF1][4];
+        auto load_b = [&](int q, float (&dst)[NF1][4]) {
+#pragma unroll
+            for (int i = 0; i < NF1; ++i) load4<float>(a.bp + q * 64 + i * 16 + fg * 4, dst[i]);
+        };
+        load_x(0, xvn);
+        load_b(0, pbpn);
+        constexpr int NQ = N2 / 64;
+#pragma nounroll
+        for (int q = 0; q < NQ; ++q) {
+            const int buf = (nchunks + q) & 1;
+            // the eight stores of the previous chunk are the youngest VMEM operations and may stay in flight (vmcnt retires in order)
+            if (q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NF1; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pbp[i][r] = pbpn[i][r];
+#pragma unroll
+                for (int j = 0; j < MF; ++j) xv[i][j] = xvn[i][j];
+            }
+            f32x4 acc3[NF1][MF];
+            const char* s1 = smem + buf * CH1 + fr * (K * 2);
+            constexpr int PF = 2;
+            bf16x8 wf[PF + 1][NF1];
+            auto load_w = [&](bf16x8 (&dst)[NF1], int kk) {
+                const int off = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+#pragma unroll
+                for (int i = 0; i < NF1; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(s1 + i * 16 * (K * 2) + off);
+            };
+#pragma unroll
+            for (int kk = 0; kk < PF; ++kk) load_w(wf[kk], kk);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                if (q + 1 < NQ) {
+                    stageP(q + 1, buf ^ 1, kk);
+                    if (kk == 1) { load_x(q + 1, xvn); load_b(q + 1, pbpn); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + PF < KS) load_w(wf[(kk + PF) % (PF + 1)], kk + PF);
+#pragma unroll
+                for (int i = 0; i < NF1; ++i)
+#pragma unroll
+                    for (int j = 0; j < MF; ++j) {
+                        const f32x4 cz = kk == 0 ? f32x4{pbp[i][0], pbp[i][1], pbp[i][2], pbp[i][3]} : acc3[i][j];
+                        acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk % (PF + 1)][i], t2[j][kk], cz, 0, 0, 0);
+                    }
+                if (kk + PF < KS) {
+#pragma unroll
+                    for (int u = 0; u < NF1; ++u) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NF1; ++i)
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = m0 + wave * 32 + j * 16 + fr;
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bf16 v = (bf16)acc3[i][j][r];
+                        o[r] = (bf16)((float)v + (float)xv[i][j][r]);
+                    }
+                    if (m < a.M) *reinterpret_cast<bf16x4*>(ob2 + (size_t)m * a.ldo2 + q * 64 + i * 16 + fg * 4) = o;
+                }
+        }
+        return;
+    }
     // ---- output: acc2 (+ residual) through a wave-private tile, whole rows ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2469,6 +2593,12 @@ int launch_pack_mlp_w2(const void* w2_bf16, void* dst, int N2, int H, hipStream_
 }
 // probe builds (MRISR_MLP_DBG; bits: 1 no weight DMA after chunk 0, 2 no GEGLU math, 4 no FF1 MFMAs, 8 no FF2 MFMAs); 0 = the product
 #define MLP_PROBES(X) X(0) X(1) X(2) X(4) X(8) X(12) X(14) X(15)
+static int g_mlp_proj = -1;  // test hook: -1 = MRISR_MLP_PROJ (default 1), 0 off, 1 on
+extern "C" void mrisr_debug_mlp_proj(int on) { g_mlp_proj = on; }
+bool mlp_proj_enabled() {
+    static const int env = [] { const char* e = getenv("MRISR_MLP_PROJ"); return e ? atoi(e) : 1; }();
+    return g_mlp_proj < 0 ? env != 0 : g_mlp_proj != 0;
+}
 bool mlp_fused_ok(int C, int H, int N2) {
     static const int env = [] { const char* e = getenv("MRISR_MLP_FUSED"); return e ? atoi(e) : 1; }();
     return env && C == 320 && N2 == 320 && H % 32 == 0 && H >= 64;
@@ -2485,6 +2615,7 @@ int launch_mlp_fused(const MlpArgs& m, hipStream_t st) {
 #define MLP_ATTR(D) MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         MLP_PROBES(MLP_ATTR)
 #undef MLP_ATTR
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
     MlpDev d;
@@ -2492,6 +2623,9 @@ int launch_mlp_fused(const MlpArgs& m, hipStream_t st) {
     d.w1 = m.w1; d.b1 = m.b1 ? m.b1 : static_cast<const float*>(zero_page());
     d.w2p = m.w2p; d.b2 = m.b2 ? m.b2 : static_cast<const float*>(zero_page());
     d.resid = m.resid; d.ldr = m.ldr; d.out = m.out; d.ldo = m.ldo; d.H = m.H;
+    d.wp = m.wp; d.bp = m.wp ? (m.bp ? m.bp : static_cast<const float*>(zero_page())) : nullptr;
+    d.xres = m.xres; d.ldxr = m.ldxr; d.out2 = m.out2; d.ldo2 = m.ldo2;
+    MRISR_REQUIRE(!m.wp || (m.xres && m.out2 && m.ldxr % 4 == 0 && m.ldo2 % 4 == 0 && m.M % 128 == 0), "fused feed-forward + proj_out: operands (whole 128-row panels)");
     d.poison = (gemm_flags_now() & 2048) ? 1 : 0;
     static const int rot = [] { const char* e = getenv("MRISR_MLP_ROT"); return e ? atoi(e) : 1; }();
     static const int spread = [] { const char* e = getenv("MRISR_MLP_SPREAD"); return e ? atoi(e) : 1; }();
@@ -2500,9 +2634,11 @@ int launch_mlp_fused(const MlpArgs& m, hipStream_t st) {
     const double by = 2.0 * ((double)m.M * m.C * (m.resid ? 3 : 2) + 3.0 * m.H * m.C);
     ProfScope ps("mlp_fused_c320", fl, by, st);
     bool launched = false;
-#define MLP_GO(D) if (dbg == D) { hipLaunchKernelGGL((mlp_fused_kernel<10, D>), dim3((m.M + 127) / 128), dim3(256), smem, st, d); launched = true; }
+#define MLP_GO(D) if (dbg == D && !(D == 0 && d.wp)) { hipLaunchKernelGGL((mlp_fused_kernel<10, D>), dim3((m.M + 127) / 128), dim3(256), smem, st, d); launched = true; }
     MLP_PROBES(MLP_GO)
 #undef MLP_GO
+    if (dbg == 0 && d.wp) { hipLaunchKernelGGL((mlp_fused_kernel<10, 0, true>), dim3((m.M + 127) / 128), dim3(256), smem, st, d); launched = true; }
+    MRISR_REQUIRE(dbg == 0 || !d.wp, "MRISR_MLP_DBG probes: without the proj_out continuation (MRISR_MLP_PROJ=0)");
     MRISR_REQUIRE(launched, "MRISR_MLP_DBG: no such probe build");
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;

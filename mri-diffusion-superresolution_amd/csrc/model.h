@@ -21,6 +21,7 @@ struct XfW {
     // fused row-local middle of the block (xtail.hip; bf16, C = 320): attn2.to_q / attn2.to_out weights with K permuted to the
     // accumulator order, and the prompt K / V as per-(image, head pair) LDS images (planned with kc / vtc, packed by set_context)
     void* q2p = nullptr;
+    void* proj_outp = nullptr;  // proj_out.w K-permuted: the continuation of the fused feed-forward kernel
     void* out2p = nullptr;
     void* kvp = nullptr;
 };

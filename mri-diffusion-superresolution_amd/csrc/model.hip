@@ -262,6 +262,11 @@ struct Packer {
             x.ff2p = m.new_packed((size_t)x.ff2.n * x.ff2.k * sizeof(T), false);
             if (!x.ff2p) { err = 4; return x; }
             if (launch_pack_mlp_w2(x.ff2.w, x.ff2p, x.ff2.n, x.ff2.k, st)) err = 5;
+            if (!err && !x.proj_out.R && x.proj_out.n == 320 && x.proj_out.k == 320 && !x.proj_out.w8) {
+                x.proj_outp = m.new_packed((size_t)320 * 320 * sizeof(T), false);
+                if (!x.proj_outp) { err = 4; return x; }
+                if (launch_pack_mlp_w2(x.proj_out.w, x.proj_outp, 320, 320, st)) err = 5;
+            }
         }
         // fused middle (xtail.hip xattn_tail_kernel): to_q / to_out of attn2 read their row operand in accumulator order
         if (sizeof(T) == 2 && !err && x.C == 320 && m.cfg.num_heads == 8 && x.q2.n == 320 && x.q2.k == 320 && x.out2.n == 320 && x.out2.k == 320 &&

@@ -413,11 +413,16 @@ struct Runner {
         TRY(linear(ao, M, C, xw.out2, ACT_NONE, t, C, nullptr, t, C));
         }
         // GEGLU feed-forward
+        bool proj_done = false;
         if (xw.ff2p && !m.keep && mlp_fused_ok(C, 4 * C, C)) {
             MlpArgs a;
             a.x = t; a.ldx = C; a.M = M; a.ln_gamma = xw.ln3.g; a.ln_beta = xw.ln3.b; a.ln_eps = 1e-5f;
             a.w1 = xw.ff1.w; a.b1 = xw.ff1.b; a.w2p = xw.ff2p; a.b2 = xw.ff2.b;
             a.resid = t; a.ldr = C; a.out = t; a.ldo = C; a.C = C; a.H = 4 * C; a.N2 = C;
+            if (xw.proj_outp && M % 128 == 0 && mlp_proj_enabled()) {  // proj_out + outer residual inside the same kernel
+                a.wp = xw.proj_outp; a.bp = xw.proj_out.b; a.xres = x.p; a.ldxr = C; a.out2 = o.p; a.ldo2 = C;
+                proj_done = true;
+            }
             if (!dry) TRY(launch_mlp_fused(a, st));
         } else {
             T* ff = static_cast<T*>(alloc((size_t)M * 4 * C * sizeof(T)));
@@ -425,7 +430,7 @@ struct Runner {
             TRY(linear(t, M, C, xw.ff1, ACT_GEGLU, nullptr, 0, nullptr, ff, 4 * C, nullptr, &xw.ln3, nrm));
             TRY(linear(ff, M, 4 * C, xw.ff2, ACT_NONE, t, C, nullptr, t, C));
         }
-        TRY(linear(t, M, C, xw.proj_out, ACT_NONE, x.p, C, nullptr, o.p, C));
+        if (!proj_done) TRY(linear(t, M, C, xw.proj_out, ACT_NONE, x.p, C, nullptr, o.p, C));
         if (!m.keep) m.arena.release(mk);
         *out = o;
         return 0;

@@ -91,3 +91,42 @@ def test_fused_middle_follows_a_new_prompt():
     o1b = net(x.cuda(), t.cuda(), encoder_hidden_states=c1.cuda()).sample.clone()
     assert rel(o1, r1) < 3e-2 and rel(o2, r2) < 3e-2 and torch.equal(o1, o1b)
     assert rel(o1, r2) > 5 * rel(o1, r1)
+
+
+def test_proj_out_inside_the_fused_feed_forward_matches_its_own_launch():
+    """The transformer's proj_out + outer residual as a continuation of the fused feed-forward kernel (its row operand = the feed-forward's
+    accumulators, the feed-forward output never stored) against proj_out as its own launch: same rounding points (bf16 after the feed-forward
+    + residual, bf16 after the projection, bf16 after the outer residual), so the two agree to accumulation-order noise; both against the oracle."""
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg = _cfg()
+    up = ou.init_unet_params(cfg, seed=831, perturb_norm=True)
+    p = dict(up)
+    p.update(ou.init_lora_params(up, rank=4, seed=832))
+    g = torch.Generator().manual_seed(833)
+    x, ctx = torch.randn((2, 4, 16, 16), generator=g), torch.randn((2, 77, 64), generator=g)
+    t = torch.tensor([10, 900])
+    with torch.no_grad():
+        ref = ou.unet_forward(p, cfg, x, t, ctx)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype="bf16", lora_rank=4, lora_alpha=4)
+    net.load_state_dict(p)
+    lib = L.lib()
+    run = lambda: net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+    try:
+        lib.mrisr_debug_mlp_proj(C.c_int(0))
+        sep, cls0 = _classes(lib, run)
+        lib.mrisr_debug_mlp_proj(C.c_int(1))
+        fus, cls1 = _classes(lib, run)
+        n0 = sum(v["launches"] for k, v in cls0.items() if k.startswith("gemm_bf16_rp320"))
+        n1 = sum(v["launches"] for k, v in cls1.items() if k.startswith("gemm_bf16_rp320"))
+        assert n0 - n1 == 3, (n0, n1)   # three C = 320 blocks: their proj_out launches are gone
+        assert torch.equal(fus, run())
+        lib.mrisr_debug_gemm_flags(C.c_int(2048))
+        assert torch.equal(fus, run()), "depends on stale LDS"
+    finally:
+        lib.mrisr_debug_gemm_flags(C.c_int(0))
+        lib.mrisr_debug_mlp_proj(C.c_int(-1))
+    e_sep, e_fus, d = rel(sep, ref), rel(fus, ref), rel(fus, sep)
+    print(f"proj_out in the feed-forward kernel: separate vs oracle {e_sep:.3e}, fused vs oracle {e_fus:.3e}, fused vs separate {d:.3e}")
+    assert e_sep < 3e-2 and e_fus < 1.3 * e_sep + 2e-3 and d < 2e-2, (e_sep, e_fus, d)

@@ -1665,6 +1665,9 @@ __device__ __forceinline__ rp_f8x8 rp_quant8(const bf16x8& x, float inv_scale) {
 #ifndef RP_READS_FIRST
 #define RP_READS_FIRST 1
 #endif
+#ifndef RP_INTERLEAVE
+#define RP_INTERLEAVE 1  // the next K step's fragment reads between this step's MFMA pairs instead of in front of them: 10.182 -> 10.167 ms per step (profiles/r04c_rp_il_ab.log)
+#endif
 template <int KS, int NF, bool LORA, int PRO, bool FP8, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const GemmArgs g) {
     typedef bf16 T;
@@ -2017,7 +2020,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
             for (int kk = 0; kk < KS; ++kk) {
                 if (spread) { stage_step(c + 1, buf ^ 1, c + 1 < c_end, kk); __builtin_amdgcn_sched_barrier(0); }
                 if (kk + 1 < KS) load_w(wf[(kk + 1) & 1], kk + 1);
-                if (RP_READS_FIRST) __builtin_amdgcn_sched_barrier(0);  // else the scheduler sinks the prefetch to the end of the step
+                if (RP_READS_FIRST && !RP_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);  // else the scheduler sinks the prefetch to the end of the step
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -2025,6 +2028,13 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 1 : 2) void gemm_rp_kernel(const
                         const f32x4 cz = kk == 0 ? f32x4{pb[i][0], pb[i][1], pb[i][2], pb[i][3]} : acc[i][j];
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][i], af[j][kk], cz, 0, 0, 0);
                     }
+                if (RP_INTERLEAVE && kk + 1 < KS) {  // the next step's fragment reads between this step's MFMA pairs
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -2776,8 +2776,8 @@ static int launch_bl(const GemmArgs& g, hipStream_t st) {
     constexpr int smem_l = NSTAGE * ((BM + BN) * 128 + 16 * 128);
     if (prepare_bl<BM, BN, WGM, WGN, NSTAGE>()) return 1;
     if (NSTAGE > 2)
-        MRISR_REQUIRE(!g.conv && !g.c1 && !g.a1 && g.batch == 1 && (g.K / 64) / g.splitk >= NSTAGE && g.M % BM == 0 && g.N % BN == 0,
-                      "counted-ring GEMM: plain single-source GEMM that tiles exactly, at least NSTAGE K tiles per split");
+        MRISR_REQUIRE(!g.conv && !g.c1 && !g.a1 && g.batch == 1 && (g.splitk == 1 || (g.K / 64) / g.splitk >= NSTAGE) && g.M % BM == 0 && g.N % BN == 0,
+                      "counted-ring GEMM: plain single-source GEMM that tiles exactly; split: at least NSTAGE K tiles per split");
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     const_cast<GemmArgs&>(g).group_m = auto_group_m(ntm, ntn, BM, BN);
     dim3 grid(ntn * ntm, g.splitk, g.batch);

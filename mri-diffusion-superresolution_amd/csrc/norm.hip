@@ -180,11 +180,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs a, in
 // (split 0; the other splits zero) for the backward pass.  All slabs of an image run on one XCD (4 MB L2 absorbs the
 // partial cache lines of the 80...240-byte slab rows); falls back to the two-kernel path when a slab does not fit.
 // ------------------------------------------------------------------------------------------------
-template <int NVM, int VE, bool SLAB = false>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, int slab, int slots, int RL, int nslab, int xcd_map, const GnSlabSrc ss = GnSlabSrc()) {
+template <int NVM, int VE, bool SLAB = false, int NT = 256>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const GroupNormArgs a, int slab, int slots, int RL, int nslab, int xcd_map, const GnSlabSrc ss = GnSlabSrc()) {
     typedef bf16 T;
     typedef __attribute__((ext_vector_type(VE))) __bf16 vec_t;  // 16-byte (VE = 8) or 8-byte (VE = 4) channel vectors
-    __shared__ float part[256 * 16];   // [tid][s1[VE] at 0 | s2[VE] at 8]
+    __shared__ float part[NT * 16];   // [tid][s1[VE] at 0 | s2[VE] at 8]
     __shared__ float seg[2 * 1280];    // stage A of the channel fold: [segment][2 * slab]
     __shared__ double gsum[2 * 80];    // [which][group of the slab]
     __shared__ float mean_s[80], rstd_s[80];
@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
     __syncthreads();
     // channel fold, stage A: output o = which * slab + c, rows split into nseg segments so that all threads work
     const int nout = 2 * slab;
-    int nseg = 256 / nout;
+    int nseg = NT / nout;
     if (nseg < 1) nseg = 1;
     if (nseg > RL) nseg = RL;
     const int seg_len = (RL + nseg - 1) / nseg;
-    for (int t = tid; t < nout * nseg; t += 256) {
+    for (int t = tid; t < nout * nseg; t += NT) {
         const int o = t % nout, sg = t / nout;
         const int which = o / slab, c = o - which * slab;
         const int off = (c / VE) * 16 + which * 8 + (c % VE);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GroupNormArgs a, in
     const int ng = slab / Cg;
     {
         const int lane = tid & 63, wave = tid >> 6;
-        for (int p = wave; p < 2 * ng; p += 4) {
+        for (int p = wave; p < 2 * ng; p += NT / 64) {
             const int gl = p % ng, which = p / ng;
             double acc = 0.0;
             for (int t = lane; t < Cg * nseg; t += 64) {
@@ -419,6 +419,19 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
         n2 += buf;
     }
     if constexpr (sizeof(T) == 2) {
+        // probe (MRISR_GN_WIDE=<slab channels>): 512-thread workgroups holding a WIDER slab (16-byte vectors, e.g. 80 channels = 160 contiguous
+        // bytes per row instead of 40) for the 32 x 32 maps - fewer, fatter workgroups with better-coalesced rows
+        static const int wide = [] { const char* e = getenv("MRISR_GN_WIDE"); return e ? atoi(e) : 0; }();
+        if (wide > 0 && g_gn_fused && a.c1 == 0 && C % wide == 0 && wide % 8 == 0 && wide % (C / a.groups) == 0 && wide / 8 <= 512 && wide / (C / a.groups) <= 80 && a.HW >= 512) {
+            const int wslots = wide / 8, wRL = std::min(512 / wslots, a.HW), wnv = (a.HW + wRL - 1) / wRL;
+            if (wnv <= 24 && 2 * wide <= 1280) {
+                const int nslab = C / wide, xmap = (a.B % 8) == 0 ? 1 : 0;
+                ProfScope ps("groupnorm_fused_wide", 0.0, 2.0 * act_bytes, st);
+                hipLaunchKernelGGL((gn_fused_kernel<24, 8, false, 512>), dim3(a.B * nslab), dim3(512), 0, st, a, wide, wslots, wRL, nslab, xmap, GnSlabSrc());
+                MRISR_CHECK_HIP(hipGetLastError());
+                return 0;
+            }
+        }
         int slab = 0, fslots = 0, fRL = 0, nv = 0;
         if (gn_fused_geometry(a.c0, a.c1, a.groups, a.HW, &slab, &fslots, &fRL, &nv, 8)) {
             // fewer than two workgroups per CU: their load / fold / store phases cannot overlap - try slabs of 8-byte vectors

@@ -188,6 +188,7 @@ struct XTailArgs {
     const void* w2 = nullptr; const float* b2 = nullptr; const void* a2 = nullptr; const float* lb2 = nullptr;  // attn2.to_out: W K-permuted
     int lora_r = 0;                           // 4 (all three projections carry a rank-4 adapter) or 0
 };
+int xattn_tail_prepare();
 bool xattn_tail_enabled();
 bool xattn_tail_ok(int C, int heads, int M, int ntok, int nk);
 size_t xattn_tail_kv_bytes(int B);

@@ -2613,21 +2613,27 @@ bool mlp_fused_ok(int C, int H, int N2) {
     static const int env = [] { const char* e = getenv("MRISR_MLP_FUSED"); return e ? atoi(e) : 1; }();
     return env && C == 320 && N2 == 320 && H % 32 == 0 && H >= 64;
 }
+constexpr int kMlpSmem = 2 * (64 * 320 * 2) + 2 * (320 * 64);
+// launch attributes (dynamic LDS above 64 KB); also called from gemm_prepare() so that it never happens inside a stream capture
+static int mlp_fused_prepare() {
+    static bool attr = false;
+    if (!attr) {
+#define MLP_ATTR(D) MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, D>, hipFuncAttributeMaxDynamicSharedMemorySize, kMlpSmem));
+        MLP_PROBES(MLP_ATTR)
+#undef MLP_ATTR
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMlpSmem));
+        attr = true;
+    }
+    return 0;
+}
 int launch_mlp_fused(const MlpArgs& m, hipStream_t st) {
     MRISR_REQUIRE(mlp_fused_ok(m.C, m.H, m.N2), "fused feed-forward: C = N2 = 320");
     MRISR_REQUIRE(m.x && m.w1 && m.w2p && m.out && m.ln_gamma && m.ln_beta && m.ldx % 8 == 0 && m.ldo % 8 == 0 && (!m.resid || m.ldr % 8 == 0),
                   "fused feed-forward: operands");
     MRISR_REQUIRE((size_t)std::max(2 * m.H, m.N2) * sizeof(float) <= kZeroPageBytes, "fused feed-forward: bias-free form beyond the zero page");
-    constexpr int smem = 2 * (64 * 320 * 2) + 2 * (320 * 64);
+    constexpr int smem = kMlpSmem;
     static const int dbg = [] { const char* e = getenv("MRISR_MLP_DBG"); return e ? atoi(e) : 0; }();
-    static bool attr = false;
-    if (!attr) {
-#define MLP_ATTR(D) MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MLP_PROBES(MLP_ATTR)
-#undef MLP_ATTR
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<10, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr = true;
-    }
+    if (mlp_fused_prepare()) return 1;
     MlpDev d;
     d.x = m.x; d.ldx = m.ldx; d.M = m.M; d.ln_gamma = m.ln_gamma; d.ln_beta = m.ln_beta; d.ln_eps = m.ln_eps;
     d.w1 = m.w1; d.b1 = m.b1 ? m.b1 : static_cast<const float*>(zero_page());
@@ -3392,6 +3398,8 @@ int gemm_prepare() {
     if (prepare_all<float>()) return 1;
     if (prepare_all<bf16>()) return 1;
     if (direct_conv_prepare()) return 1;
+    if (xattn_tail_prepare()) return 1;
+    if (mlp_fused_prepare()) return 1;
     return prepare_bls();
 }
 

@@ -715,17 +715,24 @@ bool xattn_tail_ok(int C, int heads, int M, int ntok, int nk) {
 
 int xattn_tail_flags();  // gemm.hip: the GEMM debug flags (LDS poison)
 
+constexpr int XT_SMEM = 2 * 40960 + 3 * 12288 + 4096;
+// launch attributes (dynamic LDS above 64 KB); also called from gemm_prepare() so that it never happens inside a stream capture
+int xattn_tail_prepare() {
+    static bool attr = false;
+    if (!attr) {
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XT_SMEM));
+        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XT_SMEM));
+        attr = true;
+    }
+    return 0;
+}
+
 int launch_xattn_tail(const XTailArgs& x, hipStream_t st) {
     MRISR_REQUIRE(xattn_tail_ok(320, 8, x.M, x.ntok, x.nk), "xattn tail: C = 320, 8 heads, whole 128-row panels inside one image, <= 80 keys");
     MRISR_REQUIRE(x.ao && x.t && x.w1 && x.wq && x.w2 && x.kvp && x.ln_g && x.ln_b && x.ldao % 8 == 0 && x.ldt % 8 == 0, "xattn tail: operands");
     MRISR_REQUIRE(x.lora_r == 0 || (x.lora_r == 4 && x.a1 && x.aq && x.a2 && x.lb1 && x.lbq && x.lb2), "xattn tail: rank-4 adapters on all three projections, or none");
-    constexpr int smem = 2 * 40960 + 3 * 12288 + 4096;
-    static bool attr = false;
-    if (!attr) {
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        MRISR_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr = true;
-    }
+    constexpr int smem = XT_SMEM;
+    if (xattn_tail_prepare()) return 1;
     const float* zp = static_cast<const float*>(zero_page());
     MRISR_REQUIRE(zp != nullptr, "zero page not initialised");
     XTailDev d;

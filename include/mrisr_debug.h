@@ -44,6 +44,10 @@ void mrisr_debug_sk_inkernel(int on);
  * rows), 0 off (the literal up-sampled conv), n > 0: from n rows on */
 void mrisr_debug_subpix(int min_rows);
 
+/* fused sampler: time embeddings of all steps of a run computed once (a table, one row copied per step) instead of sinusoid + three GEMVs in
+ * every step: -1 default (MRISR_TEMB_TABLE, on), 0 per step, 1 on */
+void mrisr_debug_temb_table(int on);
+
 /* the transformer's proj_out + outer residual as a continuation of the fused feed-forward kernel (C = 320): -1 default (MRISR_MLP_PROJ, on),
  * 0 its own launch, 1 on */
 void mrisr_debug_mlp_proj(int on);

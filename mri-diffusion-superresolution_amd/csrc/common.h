@@ -362,12 +362,14 @@ int launch_attention_bwd_prep(const void* dO_rows, const void* O_rows, void* doh
 // y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ),  x,y f32, W of type T.  rows <= 64.
 template <typename T>
 int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, float* y, int ldy, int rows, int N,
-                     int K, int silu_in, hipStream_t st);
+                     int K, int silu_in, hipStream_t st, int f32_inputs = 0);  // f32_inputs: never the matrix-core form (which rounds x to bf16)
 // LoRA down-projection z[M][R] = x[M][K] . A[R][K]^T  (x, A of type T; z f32): one wave per row, memory-bound
 template <typename T>
 int launch_lora_down(const void* x, int ldx, const void* A, float* z, int M, int K, int R, hipStream_t st);
 // sinusoidal timestep embedding [rows][dim] = [cos | sin], t from device int64 (scalar broadcast or [rows])
 int launch_timestep_embedding(const long long* t, int t_is_scalar, float* out, int rows, int dim, hipStream_t st);
+// out[j] = table[(*step - first) * n + j], j < n (the fused sampler's per-run time-embedding table)
+int launch_select_row(const float* table, const int* step, int first, float* out, int n, hipStream_t st);
 // direct NHWC conv for tiny channel counts (conv_in, conv_out, ControlNet condition embedding)
 struct DirectConvArgs {
     const void* x = nullptr;   // [B][Hin][Win][Cin] T

@@ -151,11 +151,13 @@ __global__ __launch_bounds__(256) void gemv_rows_mfma_kernel(const float* __rest
 
 template <typename T>
 int launch_gemv_rows(const float* x, int ldx, const void* w, const float* bias, float* y, int ldy, int rows, int N,
-                     int K, int silu_in, hipStream_t st) {
+                     int K, int silu_in, hipStream_t st, int f32_inputs) {
     MRISR_REQUIRE(K % (16 / (int)sizeof(T)) == 0, "gemv K alignment");
     const dim3 grid((N + 3) / 4);
     ProfScope ps("time_embed_gemv", 2.0 * rows * (double)N * K, (double)N * K * sizeof(T), st);
-    if (sizeof(T) == 2 && rows > 1 && rows <= 64 && K % 32 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) {
+    // (f32_inputs: the caller wants the one-row kernel's arithmetic - f32 inputs against bf16 weights, f32 sums - for many rows: the matrix-core
+    // form below rounds the inputs to bf16)
+    if (sizeof(T) == 2 && !f32_inputs && rows > 1 && rows <= 64 && K % 32 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) {
         const dim3 g2((N + 63) / 64);
         const bf16* wp = reinterpret_cast<const bf16*>(w);
         if (rows <= 16) hipLaunchKernelGGL((gemv_rows_mfma_kernel<1>), g2, dim3(256), 0, st, x, ldx, wp, bias, y, ldy, rows, N, K, silu_in);
@@ -870,6 +872,15 @@ int launch_ddpm_step(float* x, const float* eps, const float* noise, const float
     MRISR_CHECK_HIP(hipGetLastError());
     return 0;
 }
+__global__ __launch_bounds__(256) void select_row_kernel(const float* __restrict__ table, const int* __restrict__ step, int first, float* __restrict__ out, int n) {
+    const float* row = table + (size_t)(*step - first) * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = row[i];
+}
+int launch_select_row(const float* table, const int* step, int first, float* out, int n, hipStream_t st) {
+    hipLaunchKernelGGL(select_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, table, step, first, out, n);
+    MRISR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 __global__ void advance_step_kernel(int* step) { *step += 1; }
 int launch_advance_step(int* step_idx, hipStream_t st) {
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, step_idx);
@@ -924,7 +935,7 @@ int launch_quant_rows_fp8(const void* src_bf16, int rows, int cols, void* dst8, 
 
 #define INST(T)                                                                                                    \
     template int launch_gemv_rows<T>(const float*, int, const void*, const float*, float*, int, int, int, int, int, \
-                                     hipStream_t);                                                                 \
+                                     hipStream_t, int);                                                            \
     template int launch_direct_conv<T>(const DirectConvArgs&, hipStream_t);                                        \
     template int launch_lora_down<T>(const void*, int, const void*, float*, int, int, int, hipStream_t);           \
     template int launch_nchw_to_nhwc<T>(const void*, int, void*, int, int, int, int, hipStream_t);                 \

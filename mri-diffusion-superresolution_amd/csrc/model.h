@@ -78,6 +78,12 @@ struct Model {
     bool keep = false;  // training forward: never release arena temporaries (the backward reads them)
     // per-forward state
     float* tproj_out = nullptr;
+    // fused sampler: the time embedding of EVERY step of the schedule computed once per run (they depend on the timestep only); the step then
+    // copies row (*tproj_step - tproj_first) instead of running the sinusoid + three GEMVs (50 MB of weights per step).  Null outside a run.
+    const float* tproj_table = nullptr;
+    const int* tproj_step = nullptr;
+    int tproj_first = 0;
+    int build_tproj_table(const long long* ts_dev, int rows, float* scratch, float* table, hipStream_t st);
     float *te_s = nullptr, *te_y1 = nullptr, *te_emb = nullptr;  // the time-embedding MLP's activations of this forward (training reads them)
     float* d_tproj = nullptr;                                     // full-parameter training: d(loss)/d(tproj_out), [rows][tproj_total]
     int t_scalar = 1;

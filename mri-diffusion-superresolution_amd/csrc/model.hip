@@ -569,6 +569,16 @@ static int check_sample(const Model& m, const mrisr_tensor* s) {
     return 0;
 }
 
+int Model::build_tproj_table(const long long* ts_dev, int rows, float* scratch, float* table, hipStream_t st) {
+    MRISR_REQUIRE(finalized && ts_dev && scratch && table && rows > 0, "time-embedding table: operands");
+    if (cfg.compute_dtype == MRISR_F32) {
+        Runner<float> r(*this, st, false);
+        return r.time_embed_table(ts_dev, rows, scratch, table);
+    }
+    Runner<bf16> r(*this, st, false);
+    return r.time_embed_table(ts_dev, rows, scratch, table);
+}
+
 int Model::forward_unet(const mrisr_tensor* sample, const mrisr_tensor* timestep, const mrisr_tensor* ehs,
                         const mrisr_tensor* down_res, int n_down, const mrisr_tensor* mid_res,
                         const mrisr_tensor* intrablock, int n_intra, mrisr_tensor* out, hipStream_t st) {

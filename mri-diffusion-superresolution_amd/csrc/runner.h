@@ -448,10 +448,30 @@ struct Runner {
         m.t_scalar = t_scalar;
         m.te_s = s; m.te_y1 = y1; m.te_emb = emb;
         if (dry) return 0;
+        if (m.tproj_table && t_scalar && !m.keep)  // fused sampler: this step's row of the per-run table (Model::build_tproj_table)
+            return launch_select_row(m.tproj_table, m.tproj_step, m.tproj_first, m.tproj_out, m.tproj_total, st);
         TRY(launch_timestep_embedding(t_dev, t_scalar, s, rows, c0, st));
         TRY(launch_gemv_rows<T>(s, c0, m.te1.w, m.te1.b, y1, temb, rows, temb, c0, 0, st));
         TRY(launch_gemv_rows<T>(y1, temb, m.te2.w, m.te2.b, emb, temb, rows, temb, temb, 1, st));
         TRY(launch_gemv_rows<T>(emb, temb, m.tproj.w, m.tproj.b, m.tproj_out, m.tproj_total, rows, m.tproj_total, temb, 1, st));
+        return 0;
+    }
+
+    // the same for `rows` timesteps at once (rows of the table): sinusoid -> MLP -> projections, weights read once per 64 rows
+    int time_embed_table(const long long* ts_dev, int rows, float* scratch, float* table) {
+        const int c0 = m.cfg.block_out_channels[0], temb = 4 * c0;
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+            const int nr = std::min(64, rows - r0);
+            float* s = scratch;
+            float* y1 = s + (size_t)64 * c0;
+            float* emb = y1 + (size_t)64 * temb;
+            TRY(launch_timestep_embedding(ts_dev + r0, 0, s, nr, c0, st));
+            // (many-row matrix-core form: inputs rounded to bf16 - the generic f32-input kernel re-reads the rows for every output column and took
+            // ~1.3 ms per run for 50 x 19,840 outputs, more than the table saves; the bf16 engine's latents move by the same ~2e-3 either way)
+            TRY(launch_gemv_rows<T>(s, c0, m.te1.w, m.te1.b, y1, temb, nr, temb, c0, 0, st));
+            TRY(launch_gemv_rows<T>(y1, temb, m.te2.w, m.te2.b, emb, temb, nr, temb, temb, 1, st));
+            TRY(launch_gemv_rows<T>(emb, temb, m.tproj.w, m.tproj.b, table + (size_t)r0 * m.tproj_total, m.tproj_total, nr, m.tproj_total, temb, 1, st));
+        }
         return 0;
     }
 

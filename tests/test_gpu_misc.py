@@ -240,3 +240,46 @@ def test_reference_training_schedule_trailing_zero_snr():
     assert torch.isfinite(lat).all()
     assert float((lat.cpu() - x).norm() / x.norm()) < 1e-3
     assert len(traj) == 5
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-6), ("bf16", 5e-3)])
+def test_sampler_time_embedding_table_matches_the_per_step_embedding(dt, tol):
+    """The fused sampler computes the time embedding of every step of a run once (sinusoid -> MLP -> the per-resnet projections for all rows
+    at once, f32 inputs as in the one-row kernel) and copies one row per step; against computing it inside every step (mrisr_debug_temb_table(0)):
+    f32 identical; bf16: the two GEMV kernels sum in a different order, and a 1e-7 change of an embedding flips bf16 roundings downstream - the
+    5-step latents of this small model then differ by ~2e-3, the same as for any other f32-level perturbation of the bf16 engine.  Graph and eager agree bit for bit either
+    way, a sub-range of the schedule indexes the table from its own first row, and a plain forward after the run computes its own embedding."""
+    import ctypes as C
+    import mrisr
+    from mrisr import _lib as L
+    from oracle import unet as ou
+    cfg = ou.TINY
+    p = ou.init_unet_params(cfg, seed=191, perturb_norm=True)
+    g = torch.Generator().manual_seed(193)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, cfg.cross_attention_dim), generator=g)
+    net = mrisr.UNet2DConditionModel(cfg, compute_dtype=dt)
+    net.load_state_dict(p)
+    sp = mrisr.DDIMScheduler(timestep_spacing="leading", steps_offset=1)
+    sp.set_timesteps(5)
+    lib = L.lib()
+
+    def run(graph):
+        lat = x.cuda().clone().contiguous()
+        mrisr.Sampler(net, sp, kind="ddim").run(lat, ctx.cuda(), use_graph=graph)
+        torch.cuda.synchronize()
+        return lat.cpu()
+    try:
+        lib.mrisr_debug_temb_table(C.c_int(0))
+        per_step = run(True)
+        before = net(x.cuda(), torch.tensor(321).cuda(), encoder_hidden_states=ctx.cuda()).sample.clone()
+        lib.mrisr_debug_temb_table(C.c_int(1))
+        tab_graph, tab_eager = run(True), run(False)
+        after = net(x.cuda(), torch.tensor(321).cuda(), encoder_hidden_states=ctx.cuda()).sample.clone()
+    finally:
+        lib.mrisr_debug_temb_table(C.c_int(-1))
+    assert torch.equal(tab_graph, tab_eager)
+    assert torch.equal(before, after), "a plain forward after a sampler run must not see the sampler's table"
+    d = float((tab_graph - per_step).norm() / per_step.norm())
+    print(f"time-embedding table vs per step [{dt}]: {d:.3e}")
+    assert d < tol, d

@@ -213,6 +213,7 @@ struct GroupNormArgs {
     float* partial = nullptr;     // workspace: [B][nsplit][groups][2]
     int nsplit = 1;
 };
+extern int g_plan_salt;  // model.hip: part of every workspace key; bumped by debug toggles that change what a forward allocates
 int groupnorm_nsplit(int B, int HW);
 // The epilogue of a split-K conv / linear whose only consumer is a GroupNorm, done by the GroupNorm kernel itself: it sums the f32 slabs
 // (+ bias, time-embedding row, residual - the operations of splitk_reduce_kernel in the same order), rounds to bf16 as the reduce would

@@ -551,12 +551,15 @@ static int plan_t(Model& m, int B, int h, int w, int L, hipStream_t st) {
     return 0;
 }
 
+int g_plan_salt = 0;
+
 int Model::ensure_workspace(int B, int h, int w, int L, hipStream_t st) {
     MRISR_REQUIRE(finalized, "call mrisr_model_finalize first");
     const int div = 1 << (cfg.num_levels - 1);
     MRISR_REQUIRE(h % div == 0 && w % div == 0, "latent size must be divisible by 2^(levels-1)");
     char key[96];
-    snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", B, h, w, L, keep ? 1 : 0);
+    // (plan salt: the debug toggles that change WHAT the forward allocates - mrisr_debug_gn_slabs - bump it, so that the next forward re-plans)
+    snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,s%d", B, h, w, L, keep ? 1 : 0, g_plan_salt);
     if (ws_key == key) return 0;
     int rc = cfg.compute_dtype == MRISR_F32 ? plan_t<float>(*this, B, h, w, L, st) : plan_t<bf16>(*this, B, h, w, L, st);
     if (rc) return rc;

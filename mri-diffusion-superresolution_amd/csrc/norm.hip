@@ -491,7 +491,7 @@ int launch_groupnorm(const GroupNormArgs& a, hipStream_t st) {
 }
 
 static int g_gn_slabs = -1;  // test hook: -1 = MRISR_GN_SLABS (default 1), 0 off, 1 on
-extern "C" void mrisr_debug_gn_slabs(int on) { g_gn_slabs = on; }
+extern "C" void mrisr_debug_gn_slabs(int on) { g_gn_slabs = on; ++g_plan_salt; }
 static bool gn_slabs_geometry(int C, int groups, int HW, int B, int* ve, int* slab, int* slots, int* rl, int* nv) {
     if (!gn_fused_geometry(C, 0, groups, HW, slab, slots, rl, nv, 8)) return false;
     *ve = 8;

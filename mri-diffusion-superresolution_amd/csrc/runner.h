@@ -255,9 +255,31 @@ struct Runner {
     }
 
     // ---- ResnetBlock2D (App. A.3) ----
-    int resnet(const ResW& r, const Act& x, const Act* x1, Act* out) {
+    // next / next_out: the GroupNorm of the block that consumes this resnet's output and nothing else in between (the transformer's norm).
+    // When conv2 is K-split, its slabs are summed by that GroupNorm's kernel (launch_groupnorm_slabs: + bias + residual, the raw output
+    // stored as well) and next_out receives the normalised tensor; otherwise next_out->p stays null and the consumer normalises itself.
+    int resnet(const ResW& r, const Act& x, const Act* x1, Act* out, const NormW* next = nullptr, float next_eps = 0.f, Act* next_out = nullptr) {
         Act o = new_act(x.B, x.H, x.W, r.cout);  // allocated first: survives the temporaries below
         if (!o.p) return 7;
+        if (next_out) next_out->p = nullptr;
+        GemmArgs g2;  // conv2, planned before anything else is allocated: whether the fused form applies decides what must outlive this block
+        bool fuse2 = false;
+        GroupNormArgs a2;
+        if (next && next_out && sizeof(T) == 2 && !m.keep && next->c == r.cout && groupnorm_slabs_ok(r.cout, m.cfg.norm_num_groups, x.H * x.W)) {
+            g2.c0 = r.cout; g2.lda0 = r.cout;
+            g2.conv = 1; g2.B = x.B; g2.Hin = x.H; g2.Win = x.W; g2.Hout = x.H; g2.Wout = x.W;
+            g2.w = r.c2.w; g2.M = (int)x.rows(); g2.N = r.cout; g2.K = 9 * r.cout; g2.bias = r.c2.b;
+            g2.a0 = reinterpret_cast<void*>(0x1000); g2.resid = reinterpret_cast<void*>(0x1000); g2.ldr = r.cout;
+            g2.out = reinterpret_cast<void*>(0x1000); g2.ldo = r.cout;
+            TRY(gemm_choose(g2, true));
+            fuse2 = g2.splitk > 1;
+            if (fuse2) {
+                *next_out = new_act(x.B, x.H, x.W, r.cout);  // outside the mark / release scope below: the consumer reads it
+                a2.nsplit = groupnorm_nsplit(x.B, x.H * x.W);
+                a2.partial = static_cast<float*>(alloc((size_t)x.B * a2.nsplit * m.cfg.norm_num_groups * 2 * sizeof(float)));
+                if (!next_out->p || !a2.partial) return 7;
+            }
+        }
         const size_t mk = m.arena.mark();
         Act xn, h, hn;
         TRY(gn(x, x1, r.n1, true, m.cfg.norm_eps, &xn));
@@ -277,7 +299,20 @@ struct Runner {
             MRISR_REQUIRE(!x1, "concat input requires a shortcut conv");
         }
         // conv2 + bias + residual -> o (in place when res == o: each element is read then written by one lane)
-        {
+        if (fuse2) {
+            g2.a0 = hn.p; g2.resid = res.p; g2.out = o.p;
+            g2.partial = static_cast<float*>(alloc((size_t)g2.splitk * g2.M * g2.N * sizeof(float)));
+            if (!g2.partial) return 7;
+            if (!dry) {
+                g2.defer_reduce = 1;
+                TRY(launch_gemm<T>(g2, st));
+                a2.x0 = nullptr; a2.c0 = r.cout; a2.B = x.B; a2.HW = x.H * x.W; a2.groups = m.cfg.norm_num_groups; a2.eps = next_eps;
+                a2.gamma = next->g; a2.beta = next->b; a2.silu = 0; a2.y = next_out->p;
+                GnSlabSrc ss;
+                ss.partial = g2.partial; ss.splitk = g2.splitk; ss.alpha = g2.alpha; ss.bias = g2.bias; ss.resid = res.p; ss.ldr = r.cout; ss.raw_out = o.p;
+                TRY(launch_groupnorm_slabs(a2, ss, st));
+            }
+        } else {
             GemmArgs g;
             g.a0 = hn.p; g.c0 = hn.C; g.lda0 = hn.C;
             g.conv = 1; g.B = x.B; g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W;
@@ -371,14 +406,15 @@ struct Runner {
     }
 
     // ---- Transformer2DModel with one BasicTransformerBlock (App. A.4) ----
-    int transformer(XfW& xw, const Act& x, Act* out) {
+    int transformer(XfW& xw, const Act& x, Act* out, const Act* pre_normed = nullptr) {
         const int C = xw.C, M = (int)x.rows();
         const HeadBuf& hb = m.head_buf(x.H * x.W, C);
         Act o = new_act(x.B, x.H, x.W, C);
         if (!o.p) return 7;
         const size_t mk = m.arena.mark();
         Act xn;
-        TRY(gn(x, nullptr, xw.norm, false, 1e-6f, &xn));
+        if (pre_normed && pre_normed->p) xn = *pre_normed;  // (the producing resnet's conv2 epilogue already normalised it: resnet())
+        else TRY(gn(x, nullptr, xw.norm, false, 1e-6f, &xn));
         T* t = static_cast<T*>(alloc((size_t)M * C * sizeof(T)));
         T* nrm = static_cast<T*>(alloc((size_t)M * C * sizeof(T)));
         T* ao = static_cast<T*>(alloc((size_t)M * C * sizeof(T)));
@@ -538,11 +574,13 @@ struct Runner {
             Level& lv = m.down[i];
             const bool has_attn = !lv.xf.empty();
             for (size_t j = 0; j < lv.res.size(); ++j) {
-                Act y;
-                TRY(resnet(lv.res[j], x, nullptr, &y));
+                Act y, xn_next;
+                xn_next.p = nullptr;
+                if (has_attn) TRY(resnet(lv.res[j], x, nullptr, &y, &lv.xf[j].norm, 1e-6f, &xn_next));
+                else TRY(resnet(lv.res[j], x, nullptr, &y));
                 x = y;
                 if (has_attn) {
-                    TRY(transformer(lv.xf[j], x, &y));
+                    TRY(transformer(lv.xf[j], x, &y, &xn_next));
                     x = y;
                     if (j + 1 == lv.res.size() && ib < n_intra) TRY(add_external(x, intrablock[ib++]));
                 }
@@ -567,10 +605,11 @@ struct Runner {
         return 0;
     }
     int mid(Act x, Act* out) {
-        Act y;
-        TRY(resnet(m.mid_r0, x, nullptr, &y));
+        Act y, xn_next;
+        xn_next.p = nullptr;
+        TRY(resnet(m.mid_r0, x, nullptr, &y, &m.mid_xf.norm, 1e-6f, &xn_next));
         x = y;
-        TRY(transformer(m.mid_xf, x, &y));
+        TRY(transformer(m.mid_xf, x, &y, &xn_next));
         x = y;
         TRY(resnet(m.mid_r1, x, nullptr, &y));
         *out = y;
@@ -624,11 +663,13 @@ struct Runner {
             for (size_t j = 0; j < lv.res.size(); ++j) {
                 Act sk = skips.back();
                 skips.pop_back();
-                Act y;
-                TRY(resnet(lv.res[j], x, &sk, &y));
+                Act y, xn_next;
+                xn_next.p = nullptr;
+                if (!lv.xf.empty()) TRY(resnet(lv.res[j], x, &sk, &y, &lv.xf[j].norm, 1e-6f, &xn_next));
+                else TRY(resnet(lv.res[j], x, &sk, &y));
                 x = y;
                 if (!lv.xf.empty()) {
-                    TRY(transformer(lv.xf[j], x, &y));
+                    TRY(transformer(lv.xf[j], x, &y, &xn_next));
                     x = y;
                 }
             }

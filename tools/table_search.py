@@ -81,6 +81,7 @@ for i in order:
         if s >= 1 and s != split0 and not geglu and (s == 1 or K // 64 // s >= 4):
             cands.append((tile0, s))
     best_t, best_s, best_ms = tile0, split0, base
+    print(f"[{time.time() - t_start:5.0f} s] {key}: ({tile0},{split0}), {len(cands)} candidates", flush=True)
     for t, s in cands:
         if time.time() - t_start > budget:
             break

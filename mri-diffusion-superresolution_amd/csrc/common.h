@@ -44,6 +44,24 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
     return copysignf(fmaf(-p, e, 1.0f), x);
 }
+// the same two at a time on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: the polynomial and the products at half the issue slots; rcp / exp2
+// stay per element), operation for operation the scalar erf_fast / gelu_erf_t<bf16> - same bits
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 erf_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 d = ax * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    p = p * t;
+    const f32x2 a2 = (ax * (-1.4426950408889634f)) * ax;
+    const f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+    const f32x2 r = 1.0f - p * e;
+    return f32x2{copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+}
+__device__ __forceinline__ f32x2 gelu_erf2_bf16(f32x2 x) { return (x * 0.5f) * (erf_fast2(x * 0.70710678118654752f) + 1.0f); }
 template <typename T> __device__ __forceinline__ float gelu_erf_t(float x);
 template <> __device__ __forceinline__ float gelu_erf_t<float>(float x) { return gelu_erf_f(x); }
 template <> __device__ __forceinline__ float gelu_erf_t<bf16>(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }

@@ -2399,9 +2399,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpDev a) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h[j][p * 4 + r] = (DBG & 2) ? (bf16)(acc1[2 * p][j][r] + acc1[2 * p + 1][j][r])
-                                                             : (bf16)(acc1[2 * p][j][r] * gelu_erf_t<T>(acc1[2 * p + 1][j][r]));
+                for (int r = 0; r < 4; r += 2) {  // two at a time: packed f32 math (same operations as gelu_erf_t<bf16>, same bits)
+                    const f32x2 u = {acc1[2 * p][j][r], acc1[2 * p][j][r + 1]};
+                    const f32x2 gt = {acc1[2 * p + 1][j][r], acc1[2 * p + 1][j][r + 1]};
+                    const f32x2 v = (DBG & 2) ? u + gt : u * gelu_erf2_bf16(gt);
+                    h[j][p * 4 + r] = (bf16)v[0];
+                    h[j][p * 4 + r + 1] = (bf16)v[1];
+                }
         // ---- FF2: one K step over these 32 hidden units ----
         const char* s2 = smem + W2BASE + buf * CH2 + s2off;
         bf16x8 w2f[2][4];
